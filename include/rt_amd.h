@@ -1,0 +1,217 @@
+/* rt_amd.h — C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * The reference (nikitakaraevv/ray-tracing-engine) has no plugin/FFI seam; the
+ * natural boundary is `void Renderer::render(Image&)` (reference
+ * source/Renderer.h:36, source/Renderer.cpp:203-272), called once from main
+ * (source/Main.cpp:224).  Everything below is what a `Renderer::render` that
+ * dispatches to the GPU binds to (see INTEGRATION.md for the host-side stub):
+ *
+ *   rt_create / rt_destroy      <- Renderer::Renderer(Scene&, ...) deep copy of the
+ *                                  scene (Renderer.cpp:15-31): flattened snapshot
+ *   rt_set_photons              <- PhotonMap + kdtree built in render()
+ *                                  (Renderer.cpp:209-213; kdtree.h:60-69 order)
+ *   rt_emit_photons             <- PhotonMap::PhotonMap (PhotonMap.h:14-50,92-155)
+ *   rt_render                   <- the spp/y/x loop + resolve (Renderer.cpp:219-271)
+ *   rt_render_device/_resolve_device : same, on caller-owned DEVICE buffers and a
+ *                                  caller stream (multi-GPU tile sharding, bench)
+ *   rt_trace                    <- RayTracer::rayTrace (RayTracer.h:27-53) test hook
+ *   rt_knn                      <- kdtree::knearest (kdtree.h:180-195) test hook
+ *
+ * Conventions: plain C, int status (0 = RT_OK), caller-owned buffers, no C++
+ * types or exceptions across the boundary, one host thread per context.  There
+ * is NO CPU fallback: every compute entry point fails with RT_ERR_NO_DEVICE if
+ * no gfx950 device is usable.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+enum {
+  RT_OK = 0,
+  RT_ERR_INVALID = 1,   /* bad argument / inconsistent scene            */
+  RT_ERR_NO_DEVICE = 2, /* no usable HIP device (never falls back to CPU) */
+  RT_ERR_HIP = 3,       /* a HIP runtime call failed                      */
+  RT_ERR_UNSUPPORTED = 4,
+  RT_ERR_STATE = 5      /* e.g. photon shading requested without photons  */
+};
+
+/* Material.h:62-64 (m_kd, m_alpha, m_albedo, m_F0) */
+typedef struct rt_material {
+  float kd, alpha;
+  float albedo[3];
+  float f0[3];
+} rt_material;
+
+/* LightSource.h:61-65; basis from the ctor (:19-33) computed by the host */
+typedef struct rt_light {
+  float position[3], color[3], vertical[3], horizontal[3], normal[3];
+  float intensity, side, factor, ac, al, aq;
+} rt_light;
+
+/* Camera.h:34-40 (m_position, m_lowerLeftCorner, m_horizontal, m_vertical) */
+typedef struct rt_camera {
+  float position[3], lower_left[3], horizontal[3], vertical[3];
+} rt_camera;
+
+/* Flattened Scene (Scene.h:27-31, Mesh.h:136-141).  Triangles are listed in the
+ * reference's (mesh, triangle) iteration order (RayTracer.h:32-35): that order
+ * is the tie-break for equal hit distances. */
+typedef struct rt_scene_desc {
+  uint32_t n_meshes, n_vertices, n_triangles, n_lights;
+  const float* vertex_pos;        /* [n_vertices][3], meshes concatenated           */
+  const float* vertex_nrm;        /* [n_vertices][3]                                */
+  const uint32_t* tri_vtx;        /* [n_triangles][3] GLOBAL vertex ids             */
+  const uint32_t* mesh_tri_begin; /* [n_meshes+1] first triangle of each mesh       */
+  const uint32_t* mesh_vtx_begin; /* [n_meshes+1] first vertex of each mesh         */
+  const rt_material* materials;   /* [n_meshes]                                     */
+  const rt_light* lights;         /* [n_lights]                                     */
+  rt_camera camera;
+} rt_scene_desc;
+
+enum { RT_MODE_RAY = 0, RT_MODE_PATH = 1 };   /* -m, Renderer.h:9-10            */
+enum { RT_RNG_LEGACY = 0, RT_RNG_PIXEL = 1 }; /* legacy = global serial engine:
+                                                 CPU oracle only, GPU refuses  */
+enum { RT_ACCEL_BVH = 0, RT_ACCEL_BRUTE = 1 };
+enum { RT_TRACE_CLOSEST = 0, RT_TRACE_ANY = 1 };
+
+typedef struct rt_options {
+  int32_t device;          /* HIP device ordinal                              */
+  uint32_t bvh_leaf_max;   /* 0 = default (4)                                 */
+  uint32_t reserved[6];
+} rt_options;
+
+typedef struct rt_params {
+  uint32_t width, height;
+  uint32_t spp;        /* -N: samples per pixel of the whole frame             */
+  uint32_t mode;       /* RT_MODE_*                                            */
+  uint32_t max_depth;  /* 3 in the reference (Renderer.cpp:245,248)            */
+  uint32_t seed;       /* stream key, include/rt_pixelmode.h                   */
+  uint32_t rng_mode;   /* RT_RNG_PIXEL                                         */
+  uint32_t accel;      /* RT_ACCEL_*                                           */
+  uint32_t use_photons;       /* 1: photon-map shading (Renderer.cpp:63-104)   */
+  uint32_t k;                 /* -k                                            */
+  uint32_t photons_requested; /* -p: density denominator (Renderer.cpp:99)     */
+  uint32_t spp_begin, spp_count; /* sample sub-range of this call; 0,0 = all   */
+  uint32_t rank, world;       /* tile ownership: this call renders the 8x8-pixel
+                                 tiles t with owner(t) == rank                 */
+  uint32_t tile;              /* ownership granule in pixels (multiple of 8)   */
+  uint32_t collect_stats;     /* 1: also count BVH nodes / triangle tests      */
+  uint32_t reserved[7];
+} rt_params;
+
+typedef struct rt_stats {
+  uint64_t samples;        /* pixel-samples integrated                          */
+  uint64_t rays_closest;   /* closest-hit casts (primary + bounce)              */
+  uint64_t rays_shadow;    /* any-hit casts                                     */
+  uint64_t knn_queries;
+  uint64_t nodes_visited;  /* 64-B BVH node records fetched (collect_stats)     */
+  uint64_t tris_tested;    /* 48-B triangle records tested (collect_stats)      */
+  uint64_t kd_visited;     /* kd-tree nodes visited (collect_stats)             */
+  double kernel_ms;        /* device time of the integrate kernel(s)            */
+  uint64_t reserved[4];
+} rt_stats;
+
+typedef struct rt_ray {
+  float origin[3], direction[3];
+} rt_ray;
+
+/* What RayTracer::rayTrace hands back (RayTracer.h:27-53) + the triangle id. */
+typedef struct rt_hit {
+  int32_t hit;         /* 0/1                                                   */
+  uint32_t mesh;       /* meshIndex                                             */
+  uint32_t tri;        /* triangle index inside the mesh                        */
+  uint32_t vtx[3];     /* `triangle`: vertex ids LOCAL to the mesh              */
+  float u, v, d;
+} rt_hit;
+
+typedef struct rt_bvh_info {
+  uint32_t n_nodes, n_tri_records, max_depth, leaf_max;
+  float pad;           /* absolute box padding used                             */
+  uint32_t reserved[3];
+} rt_bvh_info;
+
+typedef struct rt_ctx rt_ctx;
+
+int rt_abi_version(void);
+const char* rt_last_error(void);
+
+int rt_create(const rt_scene_desc* scene, const rt_options* opt, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+
+/* Photon arrays already in the host-built kd-tree (median-implicit) order. */
+int rt_set_photons(rt_ctx* ctx, const float* pos3, const float* dir3, uint32_t n);
+/* Emit photons on the GPU (pixel RNG mode, one stream per emitted photon), in
+ * emission order; out arrays sized n_requested.  *n_out = stored photons. */
+int rt_emit_photons(rt_ctx* ctx, uint32_t n_requested, uint32_t seed, float* pos3,
+                    float* dir3, float* weight, uint32_t* n_out);
+
+/* Whole frame on host buffers: background_rgb / out_rgb are [h][w][3] floats.
+ * accum_out (optional, [h][w][4]) receives {sum r,g,b, primary-hit count}. */
+int rt_render(rt_ctx* ctx, const rt_params* p, const float* background_rgb,
+              float* out_rgb, float* accum_out, rt_stats* stats);
+
+/* Accumulate this rank's tiles / sample range into d_accum ([h][w][4] floats in
+ * DEVICE memory, caller-zeroed) on `stream` (a hipStream_t, may be NULL). */
+int rt_render_device(rt_ctx* ctx, const rt_params* p, void* d_accum, void* stream,
+                     rt_stats* stats);
+/* Renderer.cpp:262-265 on device buffers: out = sum/N + bg*(N-count)/N */
+int rt_resolve_device(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
+                      const void* d_accum, const void* d_background_rgb,
+                      void* d_out_rgb, void* stream);
+
+int rt_trace(rt_ctx* ctx, const rt_ray* rays, uint32_t n, uint32_t accel,
+             uint32_t kind, rt_hit* hits);
+int rt_knn(rt_ctx* ctx, const float* query3, uint32_t n, uint32_t k,
+           uint32_t* idx_out /*[n][k]*/, float* dist_out /*[n][k]*/,
+           uint32_t* visited_out /*[n] or NULL*/);
+
+/* Inspection hooks for tests (host copies of the flattened acceleration data). */
+int rt_bvh_info_get(rt_ctx* ctx, rt_bvh_info* out);
+int rt_bvh_export(rt_ctx* ctx, void* nodes64 /*n_nodes*64 B*/, void* tris48 /*n_tri_records*48 B*/);
+/* Device-time bookkeeping: every rt_render_device launch is bracketed by a HIP
+ * event pair on its stream.  reset() forgets them; collect() synchronises the
+ * device and returns the summed kernel time of the launches since reset
+ * (at most 256 are remembered). */
+int rt_profile_reset(rt_ctx* ctx);
+int rt_profile_collect(rt_ctx* ctx, double* total_kernel_ms, uint32_t* launches);
+
+/* Unit evaluations of single device building blocks on device `device` (parity
+ * hooks for the reference's per-function golden vectors; also what the host
+ * mirror's Ray::triangleIntersect / Material::evaluateColorResponse forward to).
+ * Layouts (per element, 32-bit words unless noted):
+ *   RT_UNIT_ASIN         in: double x                     out: double rt_asin(x)
+ *   RT_UNIT_SINF/COSF    in: float x                      out: float
+ *   RT_UNIT_STREAM_SEED  in: seed,domain,index,sub        out: uint32 state
+ *   RT_UNIT_TRIANGLE     in: p0 p1 p2 origin dir (15 f)   out: hit(0/1 as float) u v t
+ *                        (out is read first: u,v,t keep their input value where
+ *                         Ray.cpp:9-24 leaves them unwritten)
+ *   RT_UNIT_BSDF         in: kd alpha albedo3 f03 n3 wi3 wo3 (17 f)  out: rgb
+ *   RT_UNIT_RAY_AT       in: camera(12 f) u v             out: origin3 dir3
+ *   RT_UNIT_LIGHT_EVAL   in: rt_light(21 f) point3        out: rgb
+ *   RT_UNIT_SAMPLERS     in: state idx N pad normal3 rt_light(21 f)  (28 words)
+ *                        out: jitter xy, hemisphere dir3, light sample3, end state, pad3 (12 words)
+ */
+enum {
+  RT_UNIT_ASIN = 0,
+  RT_UNIT_SINF = 1,
+  RT_UNIT_COSF = 2,
+  RT_UNIT_STREAM_SEED = 3,
+  RT_UNIT_TRIANGLE = 4,
+  RT_UNIT_BSDF = 5,
+  RT_UNIT_RAY_AT = 6,
+  RT_UNIT_LIGHT_EVAL = 7,
+  RT_UNIT_SAMPLERS = 8
+};
+int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,724 @@
+// rt_oracle.cpp — TEST INFRASTRUCTURE, NOT PART OF THE PRODUCT.
+//
+// A plain single-file CPU restatement of the reference's per-pixel Monte Carlo
+// hot path, used ONLY as the checker by tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+// (ray-tracing-engine_amd/) never includes, links or calls anything in here.
+//
+// Parity status: PINNED.  In legacy RNG mode (one global minstd_rand0, serial
+// scan order, libm transcendentals) this file reproduces the reference
+// program's P3 output byte-for-byte for every image in tests/golden/manifest.json
+// and every per-function vector in tests/golden/ref_vectors.json (both generated
+// from the real reference by tests/golden/make_golden.py; see tests/test_oracle_*.py).
+// In pixel RNG mode (include/rt_pixelmode.h) the SAME code runs with the engine
+// re-seeded per (pixel, sample); that is the GPU's parity target.
+//
+// Every function cites the reference lines it restates.  All arithmetic is
+// float/double exactly as the reference's types dictate; build with
+// -ffp-contract=off (oracle/Makefile).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include <omp.h>
+
+#include "rt_amd.h"
+#include "rt_pixelmode.h"
+
+namespace {
+
+// ------------------------------------------------------------------ Vec3.h:18-232
+struct V3 {
+  float x, y, z;
+};
+inline V3 v3(float a, float b, float c) { return V3{a, b, c}; }
+inline V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(float s, V3 a) { return a * s; }  // Vec3.h:300-303
+inline V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // :221-223
+inline V3 cross(V3 a, V3 b) {                                               // :226-232
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// :166-178.  (T)sqrt(double(x)) == sqrtf(x) (double rounding is innocuous for sqrt).
+inline float length(V3 a) { return sqrtf(dot(a, a)); }
+inline V3 normalize(V3 a) {
+  float l = length(a);
+  if (l == 0.f) return a;
+  float inv = 1.0f / l;
+  return v3(a.x * inv, a.y * inv, a.z * inv);
+}
+inline float dist(V3 a, V3 b) { return length(a - b); }
+inline void twoOrthogonals(V3 n, V3& u, V3& v) {  // :180-199
+  if (fabsf(n.x) < fabsf(n.y)) {
+    if (fabsf(n.x) < fabsf(n.z)) u = v3(0, -n.z, n.y);
+    else u = v3(-n.y, n.x, 0);
+  } else {
+    if (fabsf(n.y) < fabsf(n.z)) u = v3(n.z, 0, -n.x);
+    else u = v3(-n.y, n.x, 0);
+  }
+  v = cross(n, u);
+}
+
+struct Ray {
+  V3 o, d;
+};
+
+// ------------------------------------------------------------ engine, App. B
+// std::default_random_engine == minstd_rand0 (LightSource.h:6), libstdc++
+// generate_canonical / uniform_real_distribution semantics (bits/random.tcc).
+struct Engine {
+  uint32_t s;
+  uint32_t next() {
+    s = (uint32_t)(((uint64_t)s * 16807ull) % 2147483647ull);
+    return s;
+  }
+};
+inline float canonF(Engine& e) {
+  float sum = (float)(e.next() - 1u);
+  float ret = sum / 2147483648.0f;  // float(1.0f * 2147483646.0L)
+  if (ret >= 1.0f) ret = 0.99999994f;  // nextafterf(1, 0)
+  return ret;
+}
+inline double canonD(Engine& e) {
+  const double R = 2147483646.0;
+  const double R2 = 2147483646.0 * 2147483646.0;  // double(R * 2147483646.0L): exact product, one rounding
+  double sum = (double)(e.next() - 1u);
+  sum += (double)(e.next() - 1u) * R;
+  double ret = sum / R2;
+  if (ret >= 1.0) ret = 0.99999999999999988898;  // nextafter(1.0, 0.0)
+  return ret;
+}
+inline float uniformF(Engine& e, float a, float b) { return canonF(e) * (b - a) + a; }
+inline double uniformD(Engine& e, double a, double b) { return canonD(e) * (b - a) + a; }
+
+// ------------------------------------------------------------------ math mode
+enum { MATH_LIBM = 0, MATH_DET = 1 };
+struct Math {
+  int mode;
+  double asin_(double x) const { return mode == MATH_DET ? rt_asin(x) : asin(x); }
+  float cos_(float x) const { return mode == MATH_DET ? rt_cosf(x) : cosf(x); }
+  float sin_(float x) const { return mode == MATH_DET ? rt_sinf(x) : sinf(x); }
+  double pow2(double x) const { return mode == MATH_DET ? rt_pow2(x) : pow(x, 2.0); }
+  double pow5(double x) const { return mode == MATH_DET ? rt_pow5(x) : pow(x, 5.0); }
+};
+
+struct Counters {
+  uint64_t closest = 0, shadow = 0, knn = 0, tri_tests = 0, kd_visited = 0;
+};
+
+// ---------------------------------------------------------------- Ray.cpp:9-24
+inline bool triangleIntersect(const Ray& r, V3 p0, V3 p1, V3 p2, float& u, float& v,
+                              float& t) {
+  V3 edge1 = p1 - p0, edge2 = p2 - p0;
+  V3 pvec = cross(r.d, edge2);
+  float det = dot(edge1, pvec);
+  if (fabsf(det) < 0.000001f) return false;
+  float inv_det = 1.0f / det;
+  V3 tvec = r.o - p0;
+  u = dot(tvec, pvec) * inv_det;
+  V3 qvec = cross(tvec, edge1);
+  v = dot(r.d, qvec) * inv_det;
+  t = dot(edge2, qvec) * inv_det;
+  if (u < 0.f || u > 1.f) return false;
+  if (v >= 0.f && u + v <= 1.f) return true;
+  return false;
+}
+
+struct Hit {
+  bool found = false;
+  uint32_t mesh = 0, tri = 0;  // tri = global triangle id
+  float u = 0, v = 0, d = 0;
+};
+
+// ---------------------------------------------------------- RayTracer.h:27-53
+inline Hit rayTrace(const rt_scene_desc& sc, const Ray& r, Counters* c) {
+  Hit h;
+  float closest = std::numeric_limits<float>::max();
+  for (uint32_t m = 0; m < sc.n_meshes; m++)
+    for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; t++) {
+      const uint32_t* iv = sc.tri_vtx + 3 * (size_t)t;
+      float ut, vt, dt;
+      if (c) c->tri_tests++;
+      if (triangleIntersect(r, ld3(sc.vertex_pos + 3 * (size_t)iv[0]),
+                            ld3(sc.vertex_pos + 3 * (size_t)iv[1]),
+                            ld3(sc.vertex_pos + 3 * (size_t)iv[2]), ut, vt, dt)) {
+        if (dt > 0.f && dt < closest) {
+          h.found = true;
+          closest = dt;
+          h.mesh = m;
+          h.tri = t;
+          h.u = ut;
+          h.v = vt;
+          h.d = dt;
+        }
+      }
+    }
+  return h;
+}
+
+// ------------------------------------------------------------ Camera.h:27-30
+inline Ray rayAt(const rt_camera& c, float u, float v) {
+  V3 pos = ld3(c.position);
+  V3 d = ld3(c.lower_left) + u * ld3(c.horizontal) + v * ld3(c.vertical) - pos;
+  return Ray{pos, normalize(d)};
+}
+
+// ------------------------------------------------------- RayTracer.h:109-117
+inline void jitterSample(Engine& e, int sampleIdx, int nSamples, float& x, float& y) {
+  int d = int(sqrtf(float(nSamples)));
+  int j2 = sampleIdx / d;
+  int i2 = sampleIdx % d;
+  x = (float)(((double)float(i2) + uniformD(e, 0.0, 1.0)) / (double)float(d));
+  y = (float)(((double)float(j2) + uniformD(e, 0.0, 1.0)) / (double)float(d));
+}
+
+// -------------------------------------------------------- RayTracer.h:95-107
+inline V3 hsphereUniformSample(Engine& e, const Math& M, V3 normal, float maxRayAngle) {
+  const double hi = (double)(2 * maxRayAngle) / M_PI;
+  normal = normalize(normal);
+  V3 v1, v2;
+  twoOrthogonals(normal, v1, v2);
+  v1 = normalize(v1);
+  v2 = normalize(v2);
+  float theta = (float)M.asin_(uniformD(e, 0.0, hi));
+  float phi = (float)(2 * M_PI * uniformD(e, 0.0, hi));
+  V3 direction = v1 * M.cos_(phi) + v2 * M.sin_(phi);
+  direction = normalize(direction);
+  return normalize(normal * M.cos_(theta) + direction * M.sin_(theta));
+}
+const float HALF_PI_F = (float)(M_PI / 2.f);  // call sites Renderer.cpp:165, PhotonMap.h:32,128
+
+// ------------------------------------------------------ LightSource.h:46-59
+inline V3 randAreaPosition(Engine& e, const rt_light& l) {
+  // g++ draws the multiplier of m_horizontal first
+  float rh = uniformF(e, -l.side, l.side);
+  float rv = uniformF(e, -l.side, l.side);
+  return ld3(l.position) + (rv * ld3(l.vertical)) + (rh * ld3(l.horizontal));
+}
+inline float lightRadiance(const rt_light& l, V3 p) {
+  float d = dist(p, ld3(l.position));
+  return l.intensity / (l.ac + l.al * d + l.aq * d * d);
+}
+inline V3 evaluateLight(const rt_light& l, V3 p) {
+  return l.factor * ld3(l.color) * lightRadiance(l, p);
+}
+
+// ---------------------------------------------------------- Material.h:25-70
+inline float gSchlick(const rt_material& m, V3 w, V3 n) {
+  float k = (float)((double)m.alpha * sqrt(2. / M_PI));
+  return dot(n, w) / (dot(n, w) * (1 - k) + k);
+}
+inline V3 specularResponse(const rt_material& m, const Math& M, V3 n, V3 wi, V3 wo) {
+  V3 wh = normalize(wi + wo);
+  float a2 = m.alpha * m.alpha;
+  float D = (float)((double)a2 /
+                    (M_PI * M.pow2(1 + (double)(a2 - 1) * M.pow2((double)dot(n, wh)))));
+  float f5 = (float)M.pow5(1 - fmax(0.0, (double)dot(wi, wh)));
+  V3 F0 = ld3(m.f0);
+  V3 F = F0 + (v3(1.f, 1.f, 1.f) - F0) * f5;
+  float G = gSchlick(m, wi, n) * gSchlick(m, wo, n);
+  float denom = (float)(4. * (double)dot(n, wi) * (double)dot(n, wo));
+  return D * F * G / denom;
+}
+inline V3 evaluateColorResponse(const rt_material& m, const Math& M, V3 normal, V3 wi,
+                                V3 wo) {
+  V3 diffuse = ld3(m.albedo) / (float)M_PI;
+  V3 r = m.kd * diffuse +
+         (1 - m.kd) * specularResponse(m, M, normalize(normal), normalize(wi), normalize(wo));
+  if (r.x < 0.f) r.x = 0.f;
+  if (r.y < 0.f) r.y = 0.f;
+  if (r.z < 0.f) r.z = 0.f;
+  return r;
+}
+
+// -------------------------------------------- kdtree.h:60-69,87-107,180-195
+struct Photon {
+  float pos[3], dir[3], w;
+};
+struct KdTree {
+  std::vector<Photon> nodes;
+  void makeTree(size_t begin, size_t end, size_t index) {
+    if (end <= begin) return;
+    size_t n = begin + (end - begin) / 2;
+    std::nth_element(nodes.begin() + begin, nodes.begin() + n, nodes.begin() + end,
+                     [index](const Photon& a, const Photon& b) { return a.pos[index] < b.pos[index]; });
+    index = (index + 1) % 3;
+    makeTree(begin, n, index);
+    makeTree(n + 1, end, index);
+  }
+  void build() { makeTree(0, nodes.size(), 0); }
+
+  struct HE {
+    float d;
+    uint32_t idx;
+  };
+  struct Query {
+    std::vector<HE> heap;
+    double bestdist;
+    size_t visited;
+    V3 p;
+  };
+  static bool heLess(const HE& a, const HE& b) { return a.d < b.d; }  // dist_cmp_max
+  float nodeDist(uint32_t i, V3 p) const { return dist(ld3(nodes[i].pos), p); }
+
+  void knearestRec(Query& q, size_t begin, size_t end, size_t index) const {
+    if (end <= begin) return;  // root == nullptr
+    uint32_t n = (uint32_t)(begin + (end - begin) / 2);
+    ++q.visited;
+    double d = nodeDist(n, q.p);
+    if (d < q.bestdist) {
+      std::pop_heap(q.heap.begin(), q.heap.end(), heLess);
+      HE front = q.heap.front();
+      q.heap.pop_back();
+      q.bestdist = front.d;
+      q.heap.push_back(HE{(float)d, n});
+      std::push_heap(q.heap.begin(), q.heap.end(), heLess);
+    }
+    if (q.bestdist == 0) return;
+    float pc = index == 0 ? q.p.x : index == 1 ? q.p.y : q.p.z;
+    double dx = (double)(nodes[n].pos[index] - pc);
+    index = (index + 1) % 3;
+    if (dx > 0) knearestRec(q, begin, n, index);
+    else knearestRec(q, n + 1, end, index);
+    if (dx * dx >= q.bestdist) return;
+    if (dx > 0) knearestRec(q, n + 1, end, index);
+    else knearestRec(q, begin, n, index);
+  }
+  // returns false for the reference's two logic_error cases (kdtree.h:181-183)
+  bool knearest(V3 p, int k, std::vector<HE>& out, size_t* visited) const {
+    if (nodes.empty() || k <= 0 || (size_t)k > nodes.size()) return false;
+    Query q;
+    q.p = p;
+    for (int i = 0; i < k; i++) q.heap.push_back(HE{nodeDist(i, p), (uint32_t)i});
+    std::make_heap(q.heap.begin(), q.heap.end(), heLess);
+    q.visited = 0;
+    q.bestdist = q.heap[0].d;
+    knearestRec(q, 0, nodes.size(), 0);
+    std::sort_heap(q.heap.begin(), q.heap.end(), heLess);
+    out = q.heap;
+    if (visited) *visited = q.visited;
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------ integrator
+struct Ctx {
+  const rt_scene_desc& sc;
+  Math M;
+  const KdTree* tree;  // null / empty => direct lighting
+  int k;
+  int numPhotons;
+  Counters cnt;
+};
+
+inline V3 interp(const float* arr, const uint32_t* iv, float w, float u, float v) {
+  // Renderer.cpp:274-277 dotArr
+  return w * ld3(arr + 3 * (size_t)iv[0]) + u * ld3(arr + 3 * (size_t)iv[1]) +
+         v * ld3(arr + 3 * (size_t)iv[2]);
+}
+
+// Renderer.cpp:33-61 (direct) and :63-104 (photon map)
+inline V3 shade(Ctx& c, Engine& e, const Ray& ray, const Hit& h, V3& hitNormal,
+                V3& trianglePoint, bool& ok) {
+  const rt_scene_desc& sc = c.sc;
+  float w = 1.f - h.u - h.v;
+  const uint32_t* iv = sc.tri_vtx + 3 * (size_t)h.tri;
+  hitNormal = normalize(interp(sc.vertex_nrm, iv, w, h.u, h.v));
+  trianglePoint = interp(sc.vertex_pos, iv, w, h.u, h.v);
+  const rt_material& mat = sc.materials[h.mesh];
+  V3 color = v3(0.f, 0.f, 0.f);
+  if (c.tree && !c.tree->nodes.empty()) {
+    std::vector<KdTree::HE> res;
+    size_t visited = 0;
+    c.cnt.knn++;
+    if (!c.tree->knearest(trianglePoint, c.k, res, &visited)) {
+      ok = false;
+      return color;
+    }
+    c.cnt.kd_visited += visited;
+    float r = dist(ld3(c.tree->nodes[res[c.k - 1].idx].pos), trianglePoint);
+    float area = (float)(M_PI * (double)r * (double)r);
+    V3 avg = v3(0.f, 0.f, 0.f), radiance = v3(0.f, 0.f, 0.f);
+    for (const KdTree::HE& he : res) {
+      avg = avg + ld3(c.tree->nodes[he.idx].dir);
+      radiance = radiance + v3(1.f, 1.f, 1.f);
+    }
+    radiance = radiance / area;
+    radiance = radiance / (float)c.numPhotons;
+    radiance = radiance * 100.f;  // Renderer.h:45 m_factor
+    V3 bsdf = evaluateColorResponse(mat, c.M, hitNormal, normalize(avg), -ray.d);
+    color = color + radiance * bsdf;
+    return color;
+  }
+  for (uint32_t li = 0; li < sc.n_lights; li++) {
+    const rt_light& L = sc.lights[li];
+    V3 toLight = randAreaPosition(e, L) - trianglePoint;
+    c.cnt.shadow++;
+    if (rayTrace(sc, Ray{trianglePoint, toLight}, &c.cnt).found) continue;
+    V3 bsdf = evaluateColorResponse(mat, c.M, hitNormal, toLight, -ray.d);
+    V3 radiance = evaluateLight(L, trianglePoint);
+    color = color + radiance * bsdf;
+  }
+  return color;
+}
+
+// Renderer.cpp:106-141 (mode 0) and :143-201 (mode 1, recursion unrolled; the
+// reference returns c0 + (c1 + (c2 + 0)), right-nested)
+inline V3 integrate(Ctx& c, Engine& e, Ray ray, int mode, int finalDepth, bool& found,
+                    bool& ok) {
+  V3 col[8];
+  int n = 0;
+  int maxv = mode == RT_MODE_PATH ? finalDepth : 1;
+  if (maxv > 8) maxv = 8;
+  for (int depth = 0; depth < maxv; depth++) {
+    c.cnt.closest++;
+    Hit h = rayTrace(c.sc, ray, &c.cnt);
+    if (!(h.found && h.d > 0.f)) {
+      if (depth == 0) found = false;
+      break;
+    }
+    V3 hitNormal, point;
+    col[n++] = shade(c, e, ray, h, hitNormal, point, ok);
+    if (!ok) break;
+    if (mode != RT_MODE_PATH) break;
+    V3 dir = hsphereUniformSample(e, c.M, hitNormal, HALF_PI_F);
+    ray = Ray{point, dir};
+  }
+  V3 total = v3(0.f, 0.f, 0.f);
+  for (int i = n - 1; i >= 0; i--) total = col[i] + total;
+  return total;
+}
+
+inline float clamp01(float v) { return fmaxf(fminf(v, 1.f), 0.f); }  // Renderer.cpp:279-283
+
+// ---------------------------------------------------- PhotonMap.h:14-50,92-155
+struct Emitter {
+  const rt_scene_desc& sc;
+  Math M;
+  Counters* cnt;
+  // one photon; returns true and fills `out` if a particle is stored
+  bool trace(Engine& e, Ray ray, float weight, Photon& out) {
+    Photon ph{};
+    ph.w = weight;
+    bool exit = false;
+    for (int depth = 0;; depth++) {
+      if (exit) {
+        out = ph;
+        return true;
+      }
+      if (depth >= 20) return false;
+      if (cnt) cnt->closest++;
+      Hit h = rayTrace(sc, ray, cnt);
+      if (!(h.found && h.d > 0.f)) {
+        if (depth != 0) {
+          out = ph;
+          return true;
+        }
+        return false;
+      }
+      float w = 1.f - h.u - h.v;
+      const uint32_t* iv = sc.tri_vtx + 3 * (size_t)h.tri;
+      V3 hitNormal = normalize(interp(sc.vertex_nrm, iv, w, h.u, h.v));
+      V3 point = interp(sc.vertex_pos, iv, w, h.u, h.v);
+      ph.pos[0] = point.x, ph.pos[1] = point.y, ph.pos[2] = point.z;
+      ph.dir[0] = -ray.d.x, ph.dir[1] = -ray.d.y, ph.dir[2] = -ray.d.z;
+      V3 randomDirection = hsphereUniformSample(e, M, hitNormal, HALF_PI_F);
+      V3 perfect = ray.d - 2.f * (dot(ray.d, hitNormal)) * hitNormal;
+      float bsdf =
+          length(evaluateColorResponse(sc.materials[h.mesh], M, hitNormal, ray.d, randomDirection));
+      float pdf = (dot(normalize(randomDirection), normalize(perfect)) + 1.f) / 2.f;
+      ph.w *= bsdf / pdf;
+      float continueProb = fminf(ph.w, 1.f);
+      if (uniformF(e, 0.f, 1.f) > continueProb) exit = true;
+      else ph.w /= continueProb;
+      ray = Ray{point, randomDirection};
+    }
+  }
+};
+
+// legacy: one engine threaded through; pixel: one stream per emitted photon
+void emitPhotons(const rt_scene_desc& sc, const Math& M, int numOfPhotons, int rng_mode,
+                 uint32_t seed, Engine* legacy, std::vector<Photon>& list, Counters* cnt) {
+  if (numOfPhotons <= 0 || sc.n_lights == 0) return;
+  float lightPdf = 1.f / (float)sc.n_lights;
+  int perLS = (int)((float)numOfPhotons * lightPdf);
+  Emitter em{sc, M, cnt};
+  for (uint32_t li = 0; li < sc.n_lights; li++) {
+    const rt_light& L = sc.lights[li];
+    V3 lsNormal = ld3(L.normal);
+    for (int i = 0; i < perLS; i++) {
+      Engine local;
+      Engine* e = legacy;
+      if (rng_mode == RT_RNG_PIXEL) {
+        local.s = rt_stream_seed(seed, RT_STREAM_PHOTON, li * (uint32_t)perLS + (uint32_t)i, 0);
+        e = &local;
+      }
+      V3 startPosition = randAreaPosition(*e, L);
+      V3 startDirection = hsphereUniformSample(*e, M, lsNormal, HALF_PI_F);
+      float pdf = dot(normalize(startDirection), normalize(lsNormal));
+      float weight = lightRadiance(L, startPosition) / (pdf * lightPdf);
+      Photon out;
+      if (em.trace(*e, Ray{startPosition, startDirection}, weight, out)) list.push_back(out);
+    }
+  }
+}
+
+}  // namespace
+
+// =============================================================== C interface
+extern "C" {
+
+typedef struct orc_opts {
+  int32_t math_mode;        // 0 libm (reference), 1 deterministic (rt_pixelmode.h)
+  int32_t threads;          // pixel mode only; 0 = OpenMP default
+  const float* ext_photons; // optional [n][7] (pos, dir, w) ALREADY in kd order
+  uint32_t n_ext_photons;
+  uint32_t engine_state;    // legacy: initial engine state (1 = default seed)
+} orc_opts;
+
+// Whole Renderer::render (Renderer.cpp:203-272) on the flat scene.  accum_out
+// (optional) = [h][w][4] {sum rgb, primary-hit count}.
+int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
+               const float* background_rgb, float* out_rgb, float* accum_out,
+               rt_stats* stats) {
+  const uint32_t w = p->width, h = p->height, N = p->spp;
+  Math M{o ? o->math_mode : MATH_LIBM};
+  Engine legacy{o && o->engine_state ? o->engine_state : 1u};
+  Counters total;
+  KdTree tree;
+  const int world = p->world ? (int)p->world : 1;
+  const uint32_t tile = p->tile ? p->tile : 8;
+  if (o && o->ext_photons && o->n_ext_photons) {
+    tree.nodes.resize(o->n_ext_photons);
+    memcpy(tree.nodes.data(), o->ext_photons, sizeof(Photon) * (size_t)o->n_ext_photons);
+  } else if (p->use_photons && p->photons_requested > 0) {
+    // Renderer.cpp:209-213: photon map + kd-tree are built inside render()
+    emitPhotons(*sc, M, (int)p->photons_requested, p->rng_mode, p->seed, &legacy, tree.nodes,
+                &total);
+    tree.build();
+  }
+  std::vector<float> acc((size_t)w * h * 4, 0.f);
+  const uint32_t s0 = p->spp_count ? p->spp_begin : 0, s1 = p->spp_count ? p->spp_begin + p->spp_count : N;
+  int bad = 0;
+  auto sample = [&](Ctx& c, Engine& e, uint32_t x, uint32_t y, uint32_t i) {
+    float sx, sy;
+    jitterSample(e, (int)i, (int)N, sx, sy);
+    Ray ray = rayAt(sc->camera, ((float)x + sx) / (float)w, 1.f - ((float)y + sy) / (float)h);
+    bool found = true, ok = true;
+    V3 col = integrate(c, e, ray, (int)p->mode, (int)p->max_depth, found, ok);
+    if (!ok) bad = 1;
+    float* a = &acc[((size_t)y * w + x) * 4];
+    a[0] += clamp01(col.x);
+    a[1] += clamp01(col.y);
+    a[2] += clamp01(col.z);
+    if (found) a[3] += 1.f;
+  };
+  auto owned = [&](uint32_t x, uint32_t y) {
+    if (world <= 1) return true;
+    uint32_t tx = x / tile, ty = y / tile;
+    return (int)((tx + ty) % (uint32_t)world) == (int)p->rank;
+  };
+  if (p->rng_mode == RT_RNG_LEGACY) {
+    Ctx c{*sc, M, &tree, (int)p->k, (int)p->photons_requested, Counters()};
+    for (uint32_t i = s0; i < s1; i++)
+      for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) sample(c, legacy, x, y, i);
+    total.closest += c.cnt.closest, total.shadow += c.cnt.shadow, total.knn += c.cnt.knn;
+    total.tri_tests += c.cnt.tri_tests, total.kd_visited += c.cnt.kd_visited;
+  } else {
+    int nth = o && o->threads > 0 ? o->threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nth)
+    {
+      Ctx c{*sc, M, &tree, (int)p->k, (int)p->photons_requested, Counters()};
+#pragma omp for schedule(dynamic, 4)
+      for (int64_t y = 0; y < (int64_t)h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+          if (!owned(x, (uint32_t)y)) continue;
+          for (uint32_t i = s0; i < s1; i++) {
+            Engine e{rt_stream_seed(p->seed, RT_STREAM_PIXEL, (uint32_t)y * w + x, i)};
+            sample(c, e, x, (uint32_t)y, i);
+          }
+        }
+#pragma omp critical
+      {
+        total.closest += c.cnt.closest, total.shadow += c.cnt.shadow, total.knn += c.cnt.knn;
+        total.tri_tests += c.cnt.tri_tests, total.kd_visited += c.cnt.kd_visited;
+      }
+    }
+  }
+  if (bad) return RT_ERR_STATE;
+  if (accum_out) memcpy(accum_out, acc.data(), acc.size() * sizeof(float));
+  if (out_rgb && background_rgb) {
+    // Renderer.cpp:262-265 after the last pass i = N-1
+    for (size_t px = 0; px < (size_t)w * h; px++)
+      for (int ch = 0; ch < 3; ch++) {
+        float cnt = acc[px * 4 + 3];
+        out_rgb[px * 3 + ch] = acc[px * 4 + ch] / (float)N +
+                               background_rgb[px * 3 + ch] * (float)((int)N - (int)cnt) / (float)N;
+      }
+  }
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->samples = (uint64_t)(s1 - s0) * w * h;
+    stats->rays_closest = total.closest;
+    stats->rays_shadow = total.shadow;
+    stats->knn_queries = total.knn;
+    stats->tris_tested = total.tri_tests;
+    stats->kd_visited = total.kd_visited;
+  }
+  return RT_OK;
+}
+
+int orc_trace(const rt_scene_desc* sc, const rt_ray* rays, uint32_t n, rt_hit* hits) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; i++) {
+    Hit h = rayTrace(*sc, Ray{ld3(rays[i].origin), ld3(rays[i].direction)}, nullptr);
+    rt_hit& o = hits[i];
+    memset(&o, 0, sizeof(o));
+    o.hit = h.found;
+    if (h.found) {
+      o.mesh = h.mesh;
+      o.tri = h.tri - sc->mesh_tri_begin[h.mesh];
+      for (int j = 0; j < 3; j++) o.vtx[j] = sc->tri_vtx[3 * (size_t)h.tri + j] - sc->mesh_vtx_begin[h.mesh];
+      o.u = h.u, o.v = h.v, o.d = h.d;
+    }
+  }
+  return RT_OK;
+}
+
+// Photon emission in emission order; out = [cap][7]; engine_state in/out for legacy.
+int orc_emit_photons(const rt_scene_desc* sc, uint32_t n_requested, uint32_t rng_mode, uint32_t seed,
+                     int32_t math_mode, uint32_t* engine_state, float* out7, uint32_t cap,
+                     uint32_t* n_out, uint64_t* rays_out) {
+  Math M{math_mode};
+  Engine e{engine_state && *engine_state ? *engine_state : 1u};
+  std::vector<Photon> list;
+  Counters cnt;
+  emitPhotons(*sc, M, (int)n_requested, (int)rng_mode, seed, &e, list, &cnt);
+  if (list.size() > cap) return RT_ERR_INVALID;
+  memcpy(out7, list.data(), list.size() * sizeof(Photon));
+  *n_out = (uint32_t)list.size();
+  if (engine_state) *engine_state = e.s;
+  if (rays_out) *rays_out = cnt.closest;
+  return RT_OK;
+}
+
+// kdtree::make_tree (kdtree.h:60-69): permutes [n][7] in place into tree order.
+int orc_kd_build(float* photons7, uint32_t n) {
+  KdTree t;
+  t.nodes.resize(n);
+  memcpy(t.nodes.data(), photons7, sizeof(Photon) * (size_t)n);
+  t.build();
+  memcpy(photons7, t.nodes.data(), sizeof(Photon) * (size_t)n);
+  return RT_OK;
+}
+
+int orc_knn(const float* photons7_kd, uint32_t n, const float* query3, uint32_t nq, uint32_t k,
+            uint32_t* idx_out, float* dist_out, uint32_t* visited_out) {
+  KdTree t;
+  t.nodes.resize(n);
+  memcpy(t.nodes.data(), photons7_kd, sizeof(Photon) * (size_t)n);
+  int bad = 0;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)nq; i++) {
+    std::vector<KdTree::HE> res;
+    size_t vis = 0;
+    if (!t.knearest(ld3(query3 + 3 * i), (int)k, res, &vis)) {
+      bad = 1;
+      continue;
+    }
+    for (uint32_t j = 0; j < k; j++) {
+      idx_out[(size_t)i * k + j] = res[j].idx;
+      dist_out[(size_t)i * k + j] = res[j].d;
+    }
+    if (visited_out) visited_out[i] = (uint32_t)vis;
+  }
+  return bad ? RT_ERR_STATE : RT_OK;
+}
+
+// Image::savePPM (Image.cpp:23-43) into a memory buffer; returns bytes needed.
+uint64_t orc_ppm_bytes(const float* rgb, uint32_t w, uint32_t h, char* out, uint64_t cap) {
+  std::string s = "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
+  char buf[16];
+  for (size_t i = 0; i < (size_t)w * h * 3; i++) {
+    snprintf(buf, sizeof buf, "%u ", static_cast<unsigned int>(255.f * rgb[i]));
+    s += buf;
+  }
+  s += "\n";
+  if (out && cap >= s.size()) memcpy(out, s.data(), s.size());
+  return s.size();
+}
+
+// Image::fillBackground (Image.cpp:12-21)
+void orc_fill_background(float* rgb, uint32_t w, uint32_t h) {
+  const V3 c0 = v3(0.1f, 0.2f, 0.8f), c1 = v3(0.9f, 0.9f, 1.0f);
+  for (uint32_t y = 0; y < h; y++)
+    for (uint32_t x = 0; x < w; x++) {
+      float a0 = static_cast<float>(y) / (float)(size_t)(h - 1);
+      float alpha = (a0 < 0.f) ? 0.f : (1.f < a0) ? 1.f : a0;  // std::clamp
+      V3 m = c0 * (1.0f - alpha) + c1 * alpha;  // Vec3.h:241-244 mix
+      float* o = rgb + ((size_t)y * w + x) * 3;
+      o[0] = m.x, o[1] = m.y, o[2] = m.z;
+    }
+}
+
+// ---- per-function hooks for tests/golden/ref_vectors.json
+int orc_tri_intersect(const float* p0, const float* p1, const float* p2, const float* o,
+                      const float* d, float* uvt) {
+  return triangleIntersect(Ray{ld3(o), ld3(d)}, ld3(p0), ld3(p1), ld3(p2), uvt[0], uvt[1], uvt[2]);
+}
+void orc_ray_at(const rt_camera* c, float u, float v, float* o3, float* d3) {
+  Ray r = rayAt(*c, u, v);
+  o3[0] = r.o.x, o3[1] = r.o.y, o3[2] = r.o.z;
+  d3[0] = r.d.x, d3[1] = r.d.y, d3[2] = r.d.z;
+}
+void orc_bsdf(const rt_material* m, int32_t math_mode, const float* n, const float* wi,
+              const float* wo, float* out3) {
+  V3 r = evaluateColorResponse(*m, Math{math_mode}, ld3(n), ld3(wi), ld3(wo));
+  out3[0] = r.x, out3[1] = r.y, out3[2] = r.z;
+}
+void orc_eval_light(const rt_light* l, const float* p, float* out3) {
+  V3 r = evaluateLight(*l, ld3(p));
+  out3[0] = r.x, out3[1] = r.y, out3[2] = r.z;
+}
+uint32_t orc_engine_next(uint32_t* state) {
+  Engine e{*state};
+  uint32_t v = e.next();
+  *state = e.s;
+  return v;
+}
+void orc_jitter(uint32_t* state, int32_t idx, int32_t n, float* xy) {
+  Engine e{*state};
+  jitterSample(e, idx, n, xy[0], xy[1]);
+  *state = e.s;
+}
+void orc_rand_area(uint32_t* state, const rt_light* l, float* out3) {
+  Engine e{*state};
+  V3 r = randAreaPosition(e, *l);
+  *state = e.s;
+  out3[0] = r.x, out3[1] = r.y, out3[2] = r.z;
+}
+void orc_hsphere(uint32_t* state, int32_t math_mode, const float* n, float* out3) {
+  Engine e{*state};
+  V3 r = hsphereUniformSample(e, Math{math_mode}, ld3(n), HALF_PI_F);
+  *state = e.s;
+  out3[0] = r.x, out3[1] = r.y, out3[2] = r.z;
+}
+double orc_det_asin(double x) { return rt_asin(x); }
+float orc_det_sinf(float x) { return rt_sinf(x); }
+float orc_det_cosf(float x) { return rt_cosf(x); }
+uint32_t orc_stream_seed(uint32_t seed, uint32_t domain, uint32_t index, uint32_t sub) {
+  return rt_stream_seed(seed, domain, index, sub);
+}
+
+}  // extern "C"

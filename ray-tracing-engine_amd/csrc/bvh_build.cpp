@@ -1,0 +1,233 @@
+// bvh_build.cpp — binned-SAH top-down build, see bvh_build.h.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+namespace rtbvh {
+namespace {
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() {
+    for (int a = 0; a < 3; ++a) lo[a] = std::numeric_limits<float>::infinity(), hi[a] = -lo[a];
+  }
+  void grow(const float* p) {
+    for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], p[a]), hi[a] = std::max(hi[a], p[a]);
+  }
+  void grow(const Box& b) {
+    for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], b.lo[a]), hi[a] = std::max(hi[a], b.hi[a]);
+  }
+  float halfArea() const {
+    float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    if (d[0] < 0.f) return 0.f;
+    return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+  }
+};
+
+struct Prim {
+  Box box;
+  float c[3];
+  uint32_t id;
+};
+
+struct Builder {
+  const rt_scene_desc& sc;
+  std::vector<Prim> prims;
+  Built& out;
+  uint32_t leafMax;
+
+  Builder(const rt_scene_desc& s, Built& o, uint32_t lm) : sc(s), out(o), leafMax(lm) {}
+
+  Box boundsOf(uint32_t b, uint32_t e) const {
+    Box r;
+    r.reset();
+    for (uint32_t i = b; i < e; ++i) r.grow(prims[i].box);
+    return r;
+  }
+
+  // levels needed to split n primitives into leaves of <= leafMax by halving
+  int levelsFor(uint32_t n) const {
+    int l = 0;
+    while (n > leafMax) n = (n + 1) / 2, ++l;
+    return l;
+  }
+
+  // Chooses a split of [b,e) and partitions prims; returns the middle index.
+  uint32_t split(uint32_t b, uint32_t e, int depth) {
+    const uint32_t n = e - b;
+    const uint32_t median = b + n / 2;
+    Box cb;
+    cb.reset();
+    for (uint32_t i = b; i < e; ++i) cb.grow(prims[i].c);
+    int axisOrder[3] = {0, 1, 2};
+    std::sort(axisOrder, axisOrder + 3, [&](int x, int y) { return cb.hi[x] - cb.lo[x] > cb.hi[y] - cb.lo[y]; });
+    auto medianSplit = [&]() {
+      const int ax = axisOrder[0];
+      std::nth_element(prims.begin() + b, prims.begin() + median, prims.begin() + e,
+                       [ax](const Prim& p, const Prim& q) { return p.c[ax] < q.c[ax] || (p.c[ax] == q.c[ax] && p.id < q.id); });
+      return median;
+    };
+    // depth budget: once the remaining levels are only just enough for a
+    // balanced subdivision, stop trusting SAH
+    if (depth + 1 + levelsFor((n + 1) / 2) + 2 >= kMaxDepth) return medianSplit();
+
+    constexpr int NB = 16;
+    float bestCost = std::numeric_limits<float>::infinity();
+    int bestAxis = -1, bestBin = -1;
+    for (int ax = 0; ax < 3; ++ax) {
+      const float ext = cb.hi[ax] - cb.lo[ax];
+      if (!(ext > 0.f)) continue;
+      Box bb[NB];
+      uint32_t cnt[NB] = {0};
+      for (int k = 0; k < NB; ++k) bb[k].reset();
+      const float scale = NB / ext;
+      for (uint32_t i = b; i < e; ++i) {
+        int k = std::min(NB - 1, std::max(0, static_cast<int>((prims[i].c[ax] - cb.lo[ax]) * scale)));
+        bb[k].grow(prims[i].box), ++cnt[k];
+      }
+      float rightArea[NB];
+      uint32_t rightCnt[NB];
+      Box acc;
+      acc.reset();
+      uint32_t c = 0;
+      for (int k = NB - 1; k > 0; --k) {
+        acc.grow(bb[k]), c += cnt[k];
+        rightArea[k] = acc.halfArea(), rightCnt[k] = c;
+      }
+      acc.reset(), c = 0;
+      for (int k = 0; k < NB - 1; ++k) {
+        acc.grow(bb[k]), c += cnt[k];
+        if (c == 0 || rightCnt[k + 1] == 0) continue;
+        // leaves hold up to leafMax triangles: cost in units of leaf fetches
+        float cost = acc.halfArea() * std::ceil(c / static_cast<float>(leafMax)) +
+                     rightArea[k + 1] * std::ceil(rightCnt[k + 1] / static_cast<float>(leafMax));
+        if (cost < bestCost) bestCost = cost, bestAxis = ax, bestBin = k;
+      }
+    }
+    if (bestAxis < 0) return medianSplit();
+    const float ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+    const float scale = NB / ext, lo = cb.lo[bestAxis];
+    const int ax = bestAxis, bin = bestBin;
+    auto mid = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim& p) {
+      int k = std::min(NB - 1, std::max(0, static_cast<int>((p.c[ax] - lo) * scale)));
+      return k <= bin;
+    });
+    uint32_t m = static_cast<uint32_t>(mid - prims.begin());
+    if (m == b || m == e) return medianSplit();
+    // keep the tree shallow: refuse extremely lopsided SAH splits on big ranges
+    const uint32_t small = std::min(m - b, e - m);
+    if (n > 64 && small * 64 < n && depth > kMaxDepth / 2) return medianSplit();
+    return m;
+  }
+
+  // Builds the subtree for [b,e); returns a child reference and its (padded) box.
+  int32_t recurse(uint32_t b, uint32_t e, int depth, Box& boxOut) {
+    boxOut = boundsOf(b, e);
+    for (int a = 0; a < 3; ++a) boxOut.lo[a] -= out.pad, boxOut.hi[a] += out.pad;
+    out.maxDepth = std::max<uint32_t>(out.maxDepth, depth);
+    if (e - b <= leafMax) {
+      // leaf: records in ascending global id so equal-t ties inside a leaf are
+      // met lowest id first (not required for correctness, just tidy)
+      std::sort(prims.begin() + b, prims.begin() + e, [](const Prim& p, const Prim& q) { return p.id < q.id; });
+      return encodeLeaf(b, e - b);
+    }
+    if (depth >= kMaxDepth - 1) throw std::runtime_error("BVH depth budget exceeded");
+    const uint32_t m = split(b, e, depth);
+    const int32_t self = static_cast<int32_t>(out.nodes.size());
+    out.nodes.emplace_back();
+    Box b0, b1;
+    const int32_t c0 = recurse(b, m, depth + 1, b0);
+    const int32_t c1 = recurse(m, e, depth + 1, b1);
+    Node& nd = out.nodes[self];
+    for (int a = 0; a < 3; ++a) {
+      nd.lo0[a] = b0.lo[a], nd.hi0[a] = b0.hi[a];
+      nd.lo1[a] = b1.lo[a], nd.hi1[a] = b1.hi[a];
+    }
+    nd.child[0] = c0, nd.child[1] = c1;
+    nd.pad[0] = nd.pad[1] = 0;
+    return self;
+  }
+};
+
+TriRec makeRec(const rt_scene_desc& sc, uint32_t t, uint32_t mesh) {
+  TriRec r;
+  const float* p0 = sc.vertex_pos + 3 * static_cast<size_t>(sc.tri_vtx[3 * static_cast<size_t>(t) + 0]);
+  const float* p1 = sc.vertex_pos + 3 * static_cast<size_t>(sc.tri_vtx[3 * static_cast<size_t>(t) + 1]);
+  const float* p2 = sc.vertex_pos + 3 * static_cast<size_t>(sc.tri_vtx[3 * static_cast<size_t>(t) + 2]);
+  for (int a = 0; a < 3; ++a) {
+    r.p0[a] = p0[a];
+    r.e1[a] = p1[a] - p0[a];  // the float subtraction Ray.cpp:11 does per test
+    r.e2[a] = p2[a] - p0[a];
+  }
+  r.id = t, r.mesh = mesh, r.pad = 0;
+  return r;
+}
+
+}  // namespace
+
+void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out) {
+  if (leafMax == 0) leafMax = 4;
+  if (leafMax > 8) leafMax = 8;
+  if (sc.n_triangles == 0 || sc.n_triangles >= (1u << 28)) throw std::runtime_error("triangle count out of range");
+  if (sc.mesh_tri_begin[sc.n_meshes] != sc.n_triangles || sc.mesh_vtx_begin[sc.n_meshes] != sc.n_vertices)
+    throw std::runtime_error("mesh offset tables inconsistent with counts");
+  out.nodes.clear(), out.tris.clear(), out.trisRef.clear();
+  out.leafMax = leafMax, out.maxDepth = 0;
+
+  Builder B(sc, out, leafMax);
+  B.prims.resize(sc.n_triangles);
+  out.trisRef.resize(sc.n_triangles);
+  float maxAbs = 0.f;
+  for (uint32_t m = 0; m < sc.n_meshes; ++m) {
+    if (sc.mesh_tri_begin[m] > sc.mesh_tri_begin[m + 1]) throw std::runtime_error("mesh_tri_begin not monotone");
+    for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; ++t) {
+      Prim& p = B.prims[t];
+      p.id = t;
+      p.box.reset();
+      for (int k = 0; k < 3; ++k) {
+        const uint32_t v = sc.tri_vtx[3 * static_cast<size_t>(t) + k];
+        if (v < sc.mesh_vtx_begin[m] || v >= sc.mesh_vtx_begin[m + 1])
+          throw std::runtime_error("triangle references a vertex outside its mesh");
+        const float* q = sc.vertex_pos + 3 * static_cast<size_t>(v);
+        for (int a = 0; a < 3; ++a) {
+          if (!std::isfinite(q[a])) throw std::runtime_error("non-finite vertex position");
+          maxAbs = std::max(maxAbs, std::fabs(q[a]));
+        }
+        p.box.grow(q);
+      }
+      for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+      out.trisRef[t] = makeRec(sc, t, m);
+    }
+  }
+  out.pad = 6e-5f * std::max(1.f, maxAbs);
+
+  Box root;
+  if (sc.n_triangles <= leafMax) {
+    // A root node is always present (child boxes live in the parent).  The slab
+    // test cannot express an "empty" box, so tiny scenes get two real leaves:
+    // the two halves, or the single triangle twice (a duplicate test is a no-op
+    // under the strict tie-break).
+    out.nodes.emplace_back();
+    const uint32_t n = sc.n_triangles, half = n >= 2 ? n / 2 : 1;
+    Box b0, b1;
+    const int32_t c0 = B.recurse(0, half, 1, b0);
+    const int32_t c1 = n >= 2 ? B.recurse(half, n, 1, b1) : B.recurse(0, 1, 1, b1);
+    Node& nd = out.nodes[0];
+    for (int a = 0; a < 3; ++a) {
+      nd.lo0[a] = b0.lo[a], nd.hi0[a] = b0.hi[a];
+      nd.lo1[a] = b1.lo[a], nd.hi1[a] = b1.hi[a];
+    }
+    nd.child[0] = c0, nd.child[1] = c1;
+    nd.pad[0] = nd.pad[1] = 0;
+  } else {
+    B.recurse(0, sc.n_triangles, 0, root);
+  }
+  out.tris.resize(sc.n_triangles);
+  for (uint32_t i = 0; i < sc.n_triangles; ++i) out.tris[i] = out.trisRef[B.prims[i].id];
+}
+
+}  // namespace rtbvh

@@ -1,0 +1,59 @@
+// bvh_build.h — host-side builder of the flattened scene acceleration data.
+//
+// The reference's BVH (source/BVH.h, source/AABB.cpp) is dead, unlinked and has
+// different semantics from the brute-force loop that defines the result
+// (SURVEY.md §0.2, App. A.4), so nothing of it is reproduced.  This is our own
+// design for gfx950:
+//   * ONE binary BVH over all meshes (not one pointer tree per mesh);
+//   * 64-byte node records holding BOTH child boxes, so a lane fetches one
+//     128-B-line-aligned record per step and never touches a child it culls;
+//   * 48-byte triangle records (p0, e1, e2, global id, mesh) stored in leaf
+//     order, so a leaf is 1..leaf_max consecutive records;
+//   * boxes padded by an absolute epsilon and a depth bound, so the LDS
+//     traversal stack (csrc/rt_kernels.hip) has a fixed size.
+// Exactness: traversal must return what RayTracer::rayTrace (reference
+// source/RayTracer.h:27-53) returns — the closest positive t, lowest
+// (mesh, triangle) index on ties.  Any BVH does as long as no box ever culls a
+// triangle the float Möller–Trumbore test accepts; padding + a conservative
+// slab test guarantee that (DESIGN.md §BVH exactness).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "rt_amd.h"
+
+namespace rtbvh {
+
+struct alignas(16) Node {   // 64 B
+  float lo0[3], hi0[3];     // box of child 0
+  float lo1[3], hi1[3];     // box of child 1
+  int32_t child[2];         // >= 0: node index; < 0: leaf, ~child = first << 3 | (count - 1)
+  uint32_t pad[2];
+};
+static_assert(sizeof(Node) == 64, "node record must be 64 bytes");
+
+struct alignas(16) TriRec { // 48 B
+  float p0[3], e1[3], e2[3];
+  uint32_t id;              // global triangle index in reference (mesh, tri) order
+  uint32_t mesh;
+  uint32_t pad;
+};
+static_assert(sizeof(TriRec) == 48, "triangle record must be 48 bytes");
+
+constexpr int kMaxDepth = 32;      // traversal stack entries per lane
+
+inline int32_t encodeLeaf(uint32_t first, uint32_t count) { return ~static_cast<int32_t>((first << 3) | (count - 1)); }
+
+struct Built {
+  std::vector<Node> nodes;      // nodes[0] is the root
+  std::vector<TriRec> tris;     // leaf order
+  std::vector<TriRec> trisRef;  // reference order (brute-force kernel)
+  uint32_t maxDepth = 0, leafMax = 4;
+  float pad = 0.f;
+};
+
+// Throws std::runtime_error on an inconsistent scene description.
+void build(const rt_scene_desc& scene, uint32_t leafMax, Built& out);
+
+}  // namespace rtbvh

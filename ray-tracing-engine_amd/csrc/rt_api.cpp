@@ -1,0 +1,519 @@
+// rt_api.cpp — the C ABI declared in include/rt_amd.h: context lifetime, HBM
+// residency of the flattened scene, launch orchestration.  All arithmetic of the
+// hot path lives in rt_kernels.hip; nothing here computes radiance on the host
+// and nothing falls back to the CPU when a device is missing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "rt_amd.h"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// Picks the device and refuses anything that is not a gfx950 part.
+int select_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(RT_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(RT_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RT_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
+  HIP_TRY(hipSetDevice(device));
+  return RT_OK;
+}
+
+template <class T>
+int upload(T** dptr, const void* src, size_t count) {
+  *dptr = nullptr;
+  if (count == 0) return RT_OK;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dptr), count * sizeof(T)));
+  HIP_TRY(hipMemcpy(*dptr, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+struct TileKey {
+  uint32_t w = 0, h = 0, rank = 0, world = 0, tile = 0;
+  bool operator==(const TileKey& o) const {
+    return w == o.w && h == o.h && rank == o.rank && world == o.world && tile == o.tile;
+  }
+};
+
+constexpr int kEventPairs = 256;
+
+}  // namespace
+
+struct rt_ctx {
+  int device = 0;
+  rtk::DevScene S{};
+  rtbvh::Built bvh;  // host copy kept for rt_bvh_export
+  std::vector<void*> allocs;
+  float4* phPos = nullptr;
+  float4* phDir = nullptr;
+  uint32_t* dTiles = nullptr;
+  uint32_t nTiles = 0;
+  TileKey tileKey;
+  unsigned long long* dCounters = nullptr;
+  hipEvent_t ev[kEventPairs][2];
+  int evUsed = 0;
+  bool evReady = false;
+};
+
+namespace {
+
+template <class T>
+int upload_owned(rt_ctx* c, const T** field, const void* src, size_t count) {
+  T* d = nullptr;
+  int rc = upload(&d, src, count);
+  if (rc != RT_OK) return rc;
+  if (d) c->allocs.push_back(d);
+  *field = d;
+  return RT_OK;
+}
+
+int ensure_tiles(rt_ctx* c, const rt_params* p) {
+  TileKey k;
+  k.w = p->width, k.h = p->height, k.rank = p->rank, k.world = p->world ? p->world : 1;
+  k.tile = p->tile ? p->tile : 8;
+  if (c->dTiles && k == c->tileKey) return RT_OK;
+  std::vector<uint32_t> tiles;
+  const uint32_t tx8 = (k.w + 7) / 8, ty8 = (k.h + 7) / 8;
+  for (uint32_t ty = 0; ty < ty8; ++ty)
+    for (uint32_t tx = 0; tx < tx8; ++tx) {
+      const uint32_t ox = tx * 8 / k.tile, oy = ty * 8 / k.tile;
+      if (k.world > 1 && (ox + oy) % k.world != k.rank) continue;
+      tiles.push_back(tx | (ty << 16));
+    }
+  if (c->dTiles) {
+    HIP_TRY(hipFree(c->dTiles));
+    c->dTiles = nullptr;
+  }
+  int rc = upload(&c->dTiles, tiles.data(), tiles.size());
+  if (rc != RT_OK) return rc;
+  c->nTiles = static_cast<uint32_t>(tiles.size());
+  c->tileKey = k;
+  return RT_OK;
+}
+
+int check_params(const rt_ctx* c, const rt_params* p) {
+  if (!p) return fail(RT_ERR_INVALID, "params is null");
+  if (p->width == 0 || p->height == 0 || p->width > 8 * 65535u || p->height > 8 * 65535u)
+    return fail(RT_ERR_INVALID, "image size %ux%u out of range", p->width, p->height);
+  if (p->spp == 0) return fail(RT_ERR_INVALID, "spp must be >= 1");
+  if (p->mode != RT_MODE_RAY && p->mode != RT_MODE_PATH) return fail(RT_ERR_INVALID, "mode must be 0 or 1");
+  if (p->rng_mode != RT_RNG_PIXEL)
+    return fail(RT_ERR_UNSUPPORTED,
+                "rng_mode legacy is one global serial engine (reference LightSource.h:6) and cannot run in "
+                "parallel; the GPU path implements RT_RNG_PIXEL only");
+  if (p->max_depth < 1 || p->max_depth > 4) return fail(RT_ERR_UNSUPPORTED, "max_depth must be in 1..4");
+  if (p->world > 1 && p->rank >= p->world) return fail(RT_ERR_INVALID, "rank %u >= world %u", p->rank, p->world);
+  if (p->tile % 8 != 0) return fail(RT_ERR_INVALID, "tile must be a multiple of 8");
+  if (p->spp_count && (uint64_t)p->spp_begin + p->spp_count > p->spp)
+    return fail(RT_ERR_INVALID, "sample range [%u,+%u) exceeds spp %u", p->spp_begin, p->spp_count, p->spp);
+  if (p->use_photons) {
+    if (c->S.n_photons == 0) return fail(RT_ERR_STATE, "use_photons set but no photons were uploaded (rt_set_photons)");
+    if (p->k < 1 || p->k > RTK_KMAX) return fail(RT_ERR_UNSUPPORTED, "k must be in 1..%d", RTK_KMAX);
+    // kdtree.h:182-183 throws std::logic_error here
+    if (p->k > c->S.n_photons) return fail(RT_ERR_STATE, "k is greater than the number of nodes");
+    if (p->photons_requested == 0) return fail(RT_ERR_INVALID, "photons_requested must be > 0 with use_photons");
+  }
+  return RT_OK;
+}
+
+int read_counters(rt_ctx* c, rt_stats* st) {
+  unsigned long long h[RTK_CNT_COUNT];
+  HIP_TRY(hipMemcpy(h, c->dCounters, sizeof h, hipMemcpyDeviceToHost));
+  st->rays_closest = h[RTK_CNT_CLOSEST];
+  st->rays_shadow = h[RTK_CNT_SHADOW];
+  st->knn_queries = h[RTK_CNT_KNN];
+  st->nodes_visited = h[RTK_CNT_NODES];
+  st->tris_tested = h[RTK_CNT_TRIS];
+  st->kd_visited = h[RTK_CNT_KD];
+  return RT_OK;
+}
+
+// Launch the integrate kernel for p on `stream`, bracketed by an event pair.
+int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stream, int* evIndex) {
+  int rc = ensure_tiles(c, p);
+  if (rc != RT_OK) return rc;
+  rtk::RenderArgs A;
+  A.tiles = c->dTiles, A.n_tiles = c->nTiles;
+  A.width = p->width, A.height = p->height, A.spp = p->spp;
+  A.s0 = p->spp_count ? p->spp_begin : 0;
+  A.s1 = p->spp_count ? p->spp_begin + p->spp_count : p->spp;
+  A.mode = p->mode, A.max_depth = p->max_depth, A.seed = p->seed;
+  A.k = p->k, A.photons_requested = p->photons_requested;
+  const int e = c->evUsed % kEventPairs;
+  HIP_TRY(hipEventRecord(c->ev[e][0], stream));
+  hipError_t he = rtk::launch_render(p->accel == RT_ACCEL_BRUTE, p->use_photons != 0, p->collect_stats != 0, c->S, A,
+                                     dAccum, c->dCounters, stream);
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "render launch failed: %s", hipGetErrorString(he));
+  HIP_TRY(hipEventRecord(c->ev[e][1], stream));
+  c->evUsed++;
+  if (evIndex) *evIndex = e;
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
+  if (!sc || !out) return fail(RT_ERR_INVALID, "scene/out is null");
+  *out = nullptr;
+  if (!sc->vertex_pos || !sc->vertex_nrm || !sc->tri_vtx || !sc->mesh_tri_begin || !sc->mesh_vtx_begin ||
+      !sc->materials || (sc->n_lights && !sc->lights))
+    return fail(RT_ERR_INVALID, "scene descriptor has null arrays");
+  if (sc->n_meshes == 0 || sc->n_vertices == 0 || sc->n_triangles == 0)
+    return fail(RT_ERR_INVALID, "empty scene");
+  int rc = select_device(opt ? opt->device : 0);
+  if (rc != RT_OK) return rc;
+
+  rt_ctx* c = new rt_ctx();
+  c->device = opt ? opt->device : 0;
+  try {
+    rtbvh::build(*sc, opt ? opt->bvh_leaf_max : 0, c->bvh);
+  } catch (const std::exception& e) {
+    delete c;
+    return fail(RT_ERR_INVALID, "scene rejected: %s", e.what());
+  }
+  static_assert(sizeof(rtbvh::Node) == 4 * sizeof(float4), "node layout");
+  static_assert(sizeof(rtbvh::TriRec) == 3 * sizeof(float4), "triangle layout");
+  std::vector<uint4> shade(sc->n_triangles);
+  for (uint32_t m = 0; m < sc->n_meshes; ++m)
+    for (uint32_t t = sc->mesh_tri_begin[m]; t < sc->mesh_tri_begin[m + 1]; ++t)
+      shade[t] = make_uint4(sc->tri_vtx[3 * (size_t)t], sc->tri_vtx[3 * (size_t)t + 1], sc->tri_vtx[3 * (size_t)t + 2], m);
+
+  rtk::DevScene& S = c->S;
+#define UP(field, src, n)                                  \
+  if ((rc = upload_owned(c, &S.field, src, n)) != RT_OK) { \
+    rt_destroy(c);                                         \
+    return rc;                                             \
+  }
+  UP(nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4);
+  UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);
+  UP(trisRef, c->bvh.trisRef.data(), c->bvh.trisRef.size() * 3);
+  UP(triShade, shade.data(), shade.size());
+  UP(vpos, sc->vertex_pos, (size_t)sc->n_vertices * 3);
+  UP(vnrm, sc->vertex_nrm, (size_t)sc->n_vertices * 3);
+  UP(mats, sc->materials, sc->n_meshes);
+  UP(lights, sc->lights, sc->n_lights);
+  UP(meshTriBegin, sc->mesh_tri_begin, sc->n_meshes + 1);
+  UP(meshVtxBegin, sc->mesh_vtx_begin, sc->n_meshes + 1);
+#undef UP
+  S.n_tris = sc->n_triangles;
+  S.n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
+  S.n_lights = sc->n_lights;
+  S.n_photons = 0;
+  S.phPos = S.phDir = nullptr;
+  S.cam = sc->camera;
+  if (hipMalloc(reinterpret_cast<void**>(&c->dCounters), RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->dCounters, 0, RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess) {
+    rt_destroy(c);
+    return fail(RT_ERR_HIP, "counter allocation failed");
+  }
+  for (auto& pr : c->ev)
+    if (hipEventCreate(&pr[0]) != hipSuccess || hipEventCreate(&pr[1]) != hipSuccess) {
+      rt_destroy(c);
+      return fail(RT_ERR_HIP, "event creation failed");
+    }
+  c->evReady = true;
+  *out = c;
+  return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->phPos) (void)hipFree(c->phPos);
+  if (c->phDir) (void)hipFree(c->phDir);
+  if (c->dTiles) (void)hipFree(c->dTiles);
+  if (c->dCounters) (void)hipFree(c->dCounters);
+  if (c->evReady)
+    for (auto& pr : c->ev) (void)hipEventDestroy(pr[0]), (void)hipEventDestroy(pr[1]);
+  delete c;
+}
+
+int rt_set_photons(rt_ctx* c, const float* pos3, const float* dir3, uint32_t n) {
+  if (!c) return fail(RT_ERR_INVALID, "ctx is null");
+  if (n && (!pos3 || !dir3)) return fail(RT_ERR_INVALID, "photon arrays are null");
+  if (n >= (1u << 30)) return fail(RT_ERR_UNSUPPORTED, "too many photons");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->phPos) HIP_TRY(hipFree(c->phPos));
+  if (c->phDir) HIP_TRY(hipFree(c->phDir));
+  c->phPos = c->phDir = nullptr;
+  std::vector<float4> p(n), d(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    p[i] = make_float4(pos3[3 * (size_t)i], pos3[3 * (size_t)i + 1], pos3[3 * (size_t)i + 2], 0.f);
+    d[i] = make_float4(dir3[3 * (size_t)i], dir3[3 * (size_t)i + 1], dir3[3 * (size_t)i + 2], 0.f);
+  }
+  int rc = upload(&c->phPos, p.data(), n);
+  if (rc == RT_OK) rc = upload(&c->phDir, d.data(), n);
+  if (rc != RT_OK) return rc;
+  c->S.phPos = c->phPos, c->S.phDir = c->phDir, c->S.n_photons = n;
+  return RT_OK;
+}
+
+int rt_emit_photons(rt_ctx* c, uint32_t n_requested, uint32_t seed, float* pos3, float* dir3, float* weight,
+                    uint32_t* n_out) {
+  if (!c || !n_out) return fail(RT_ERR_INVALID, "ctx/n_out is null");
+  *n_out = 0;
+  if (n_requested == 0 || c->S.n_lights == 0) return RT_OK;
+  if (!pos3 || !dir3) return fail(RT_ERR_INVALID, "output arrays are null");
+  HIP_TRY(hipSetDevice(c->device));
+  // PhotonMap.h:19-20: lightPdf = 1.f / #lights; photonsPerLS = (int)(n * lightPdf)
+  const float lightPdf = 1.f / static_cast<float>(c->S.n_lights);
+  const uint32_t perLight = static_cast<uint32_t>(static_cast<int>(static_cast<float>(static_cast<int>(n_requested)) * lightPdf));
+  const uint32_t n = perLight * c->S.n_lights;
+  if (n == 0) return RT_OK;
+  float4 *dPos = nullptr, *dDir = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dPos), n * sizeof(float4)));
+  if (hipMalloc(reinterpret_cast<void**>(&dDir), n * sizeof(float4)) != hipSuccess) {
+    (void)hipFree(dPos);
+    return fail(RT_ERR_HIP, "photon buffer allocation failed");
+  }
+  hipError_t he = rtk::launch_emit(c->S, perLight, seed, dPos, dDir, c->dCounters, nullptr);
+  std::vector<float4> hp(n), hd(n);
+  if (he == hipSuccess) he = hipMemcpy(hp.data(), dPos, n * sizeof(float4), hipMemcpyDeviceToHost);
+  if (he == hipSuccess) he = hipMemcpy(hd.data(), dDir, n * sizeof(float4), hipMemcpyDeviceToHost);
+  (void)hipFree(dPos), (void)hipFree(dDir);
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "photon emission failed: %s", hipGetErrorString(he));
+  uint32_t m = 0;
+  for (uint32_t j = 0; j < n; ++j) {
+    if (hp[j].w == 0.f) continue;  // this emitted photon stored no particle
+    pos3[3 * (size_t)m] = hp[j].x, pos3[3 * (size_t)m + 1] = hp[j].y, pos3[3 * (size_t)m + 2] = hp[j].z;
+    dir3[3 * (size_t)m] = hd[j].x, dir3[3 * (size_t)m + 1] = hd[j].y, dir3[3 * (size_t)m + 2] = hd[j].z;
+    if (weight) weight[m] = hd[j].w;
+    ++m;
+  }
+  *n_out = m;
+  return RT_OK;
+}
+
+int rt_render_device(rt_ctx* c, const rt_params* p, void* d_accum, void* stream, rt_stats* stats) {
+  if (!c || !d_accum) return fail(RT_ERR_INVALID, "ctx/d_accum is null");
+  int rc = check_params(c, p);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (stats) HIP_TRY(hipMemsetAsync(c->dCounters, 0, RTK_CNT_COUNT * sizeof(unsigned long long), s));
+  int e = 0;
+  rc = launch_frame(c, p, static_cast<float4*>(d_accum), s, &e);
+  if (rc != RT_OK) return rc;
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    HIP_TRY(hipStreamSynchronize(s));
+    rc = read_counters(c, stats);
+    if (rc != RT_OK) return rc;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[e][0], c->ev[e][1]));
+    stats->kernel_ms = ms;
+    const uint32_t n = p->spp_count ? p->spp_count : p->spp;
+    // samples of the tiles this rank owns
+    stats->samples = 0;
+    if (c->nTiles) {
+      uint64_t px = 0;
+      const uint32_t tile = c->tileKey.tile, world = c->tileKey.world;
+      for (uint32_t y = 0; y < p->height; ++y)
+        for (uint32_t x = 0; x < p->width; ++x)
+          if (world <= 1 || ((x / tile) + (y / tile)) % world == p->rank) ++px;
+      stats->samples = px * n;
+    }
+  }
+  return RT_OK;
+}
+
+int rt_resolve_device(rt_ctx* c, uint32_t width, uint32_t height, uint32_t spp, const void* d_accum,
+                      const void* d_bg, void* d_out, void* stream) {
+  if (!c || !d_accum || !d_bg || !d_out) return fail(RT_ERR_INVALID, "null argument");
+  if (spp == 0) return fail(RT_ERR_INVALID, "spp must be >= 1");
+  HIP_TRY(hipSetDevice(c->device));
+  hipError_t he = rtk::launch_resolve(width * height, spp, static_cast<const float4*>(d_accum),
+                                      static_cast<const float*>(d_bg), static_cast<float*>(d_out),
+                                      static_cast<hipStream_t>(stream));
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
+int rt_render(rt_ctx* c, const rt_params* p, const float* bg, float* out_rgb, float* accum_out, rt_stats* stats) {
+  if (!c) return fail(RT_ERR_INVALID, "ctx is null");
+  int rc = check_params(c, p);
+  if (rc != RT_OK) return rc;
+  if (out_rgb && !bg) return fail(RT_ERR_INVALID, "out_rgb requested without a background image");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t npx = (size_t)p->width * p->height;
+  float4* dAccum = nullptr;
+  float *dBg = nullptr, *dOut = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAccum), npx * sizeof(float4)));
+  auto cleanup = [&]() {
+    (void)hipFree(dAccum);
+    if (dBg) (void)hipFree(dBg);
+    if (dOut) (void)hipFree(dOut);
+  };
+  hipError_t he = hipMemset(dAccum, 0, npx * sizeof(float4));
+  if (he != hipSuccess) {
+    cleanup();
+    return fail(RT_ERR_HIP, "memset failed: %s", hipGetErrorString(he));
+  }
+  rt_stats local;
+  rc = rt_render_device(c, p, dAccum, nullptr, stats ? stats : &local);
+  if (rc != RT_OK) {
+    cleanup();
+    return rc;
+  }
+  if (out_rgb) {
+    if ((he = hipMalloc(reinterpret_cast<void**>(&dBg), npx * 3 * sizeof(float))) == hipSuccess &&
+        (he = hipMalloc(reinterpret_cast<void**>(&dOut), npx * 3 * sizeof(float))) == hipSuccess &&
+        (he = hipMemcpy(dBg, bg, npx * 3 * sizeof(float), hipMemcpyHostToDevice)) == hipSuccess) {
+      rc = rt_resolve_device(c, p->width, p->height, p->spp, dAccum, dBg, dOut, nullptr);
+      if (rc == RT_OK) he = hipMemcpy(out_rgb, dOut, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    if (rc == RT_OK && he != hipSuccess) rc = fail(RT_ERR_HIP, "resolve failed: %s", hipGetErrorString(he));
+  }
+  if (rc == RT_OK && accum_out) {
+    he = hipMemcpy(accum_out, dAccum, npx * sizeof(float4), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) rc = fail(RT_ERR_HIP, "accumulator read-back failed: %s", hipGetErrorString(he));
+  }
+  cleanup();
+  return rc;
+}
+
+int rt_trace(rt_ctx* c, const rt_ray* rays, uint32_t n, uint32_t accel, uint32_t kind, rt_hit* hits) {
+  if (!c || (n && (!rays || !hits))) return fail(RT_ERR_INVALID, "null argument");
+  if (n == 0) return RT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  rt_ray* dR = nullptr;
+  rt_hit* dH = nullptr;
+  int rc = upload(&dR, rays, n);
+  if (rc != RT_OK) return rc;
+  if (hipMalloc(reinterpret_cast<void**>(&dH), n * sizeof(rt_hit)) != hipSuccess) {
+    (void)hipFree(dR);
+    return fail(RT_ERR_HIP, "hit buffer allocation failed");
+  }
+  hipError_t he = rtk::launch_trace(accel == RT_ACCEL_BRUTE, kind == RT_TRACE_ANY, c->S, dR, n, dH, c->dCounters, nullptr);
+  if (he == hipSuccess) he = hipMemcpy(hits, dH, n * sizeof(rt_hit), hipMemcpyDeviceToHost);
+  (void)hipFree(dR), (void)hipFree(dH);
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "trace failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
+int rt_knn(rt_ctx* c, const float* q3, uint32_t n, uint32_t k, uint32_t* idx, float* dist, uint32_t* visited) {
+  if (!c || (n && (!q3 || !idx || !dist))) return fail(RT_ERR_INVALID, "null argument");
+  if (c->S.n_photons == 0) return fail(RT_ERR_STATE, "tree is empty");              // kdtree.h:181
+  if (k < 1 || k > RTK_KMAX) return fail(RT_ERR_UNSUPPORTED, "k must be in 1..%d", RTK_KMAX);
+  if (k > c->S.n_photons) return fail(RT_ERR_STATE, "k is greater than the number of nodes");  // kdtree.h:182-183
+  if (n == 0) return RT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  float* dQ = nullptr;
+  uint32_t *dI = nullptr, *dV = nullptr;
+  float* dD = nullptr;
+  int rc = upload(&dQ, q3, (size_t)n * 3);
+  if (rc != RT_OK) return rc;
+  hipError_t he = hipMalloc(reinterpret_cast<void**>(&dI), (size_t)n * k * sizeof(uint32_t));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&dD), (size_t)n * k * sizeof(float));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&dV), (size_t)n * sizeof(uint32_t));
+  if (he == hipSuccess) he = rtk::launch_knn(c->S, dQ, n, k, dI, dD, dV, nullptr);
+  if (he == hipSuccess) he = hipMemcpy(idx, dI, (size_t)n * k * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  if (he == hipSuccess) he = hipMemcpy(dist, dD, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost);
+  if (he == hipSuccess && visited) he = hipMemcpy(visited, dV, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(dQ);
+  if (dI) (void)hipFree(dI);
+  if (dD) (void)hipFree(dD);
+  if (dV) (void)hipFree(dV);
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "knn failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
+int rt_bvh_info_get(rt_ctx* c, rt_bvh_info* out) {
+  if (!c || !out) return fail(RT_ERR_INVALID, "null argument");
+  memset(out, 0, sizeof *out);
+  out->n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
+  out->n_tri_records = static_cast<uint32_t>(c->bvh.tris.size());
+  out->max_depth = c->bvh.maxDepth;
+  out->leaf_max = c->bvh.leafMax;
+  out->pad = c->bvh.pad;
+  return RT_OK;
+}
+
+int rt_bvh_export(rt_ctx* c, void* nodes64, void* tris48) {
+  if (!c) return fail(RT_ERR_INVALID, "ctx is null");
+  if (nodes64) memcpy(nodes64, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node));
+  if (tris48) memcpy(tris48, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(rtbvh::TriRec));
+  return RT_OK;
+}
+
+int rt_profile_reset(rt_ctx* c) {
+  if (!c) return fail(RT_ERR_INVALID, "ctx is null");
+  c->evUsed = 0;
+  return RT_OK;
+}
+
+int rt_profile_collect(rt_ctx* c, double* total_ms, uint32_t* launches) {
+  if (!c || !total_ms || !launches) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int n = c->evUsed < kEventPairs ? c->evUsed : kEventPairs;
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]));
+    sum += ms;
+  }
+  *total_ms = sum, *launches = static_cast<uint32_t>(n);
+  return RT_OK;
+}
+
+int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint32_t n) {
+  static const uint32_t inBytes[] = {8, 4, 4, 16, 60, 68, 56, 96, 112};
+  static const uint32_t outBytes[] = {8, 4, 4, 4, 16, 12, 24, 12, 48};
+  if (which > RT_UNIT_SAMPLERS) return fail(RT_ERR_INVALID, "unknown unit %u", which);
+  if (n && (!in || !out)) return fail(RT_ERR_INVALID, "null argument");
+  if (n == 0) return RT_OK;
+  int rc = select_device(device);
+  if (rc != RT_OK) return rc;
+  void *dIn = nullptr, *dOut = nullptr;
+  HIP_TRY(hipMalloc(&dIn, (size_t)n * inBytes[which]));
+  hipError_t he = hipMalloc(&dOut, (size_t)n * outBytes[which]);
+  if (he == hipSuccess) he = hipMemcpy(dIn, in, (size_t)n * inBytes[which], hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(dOut, out, (size_t)n * outBytes[which], hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = rtk::launch_unit(which, dIn, dOut, n, nullptr);
+  if (he == hipSuccess) he = hipMemcpy(out, dOut, (size_t)n * outBytes[which], hipMemcpyDeviceToHost);
+  (void)hipFree(dIn);
+  if (dOut) (void)hipFree(dOut);
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "unit kernel failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
+}  // extern "C"

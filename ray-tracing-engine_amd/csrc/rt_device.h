@@ -1,0 +1,180 @@
+// rt_device.h — device-side building blocks of the gfx950 path integrator.
+//
+// Each function names the reference lines whose RESULT it must reproduce; the
+// code is written for the GPU (flattened records, no recursion, no containers).
+// Bit-parity rules (SURVEY.md §7 "hard parts"): this translation unit is built
+// with -ffp-contract=off, every expression keeps the reference's operand types
+// and association, division and sqrt are the correctly rounded HIP defaults,
+// and the transcendental functions come from include/rt_pixelmode.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_amd.h"
+#include "rt_pixelmode.h"
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rtd {
+
+// ------------------------------------------------------------------ 3-vectors
+struct f3 {
+  float x, y, z;
+};
+RT_DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+RT_DEV f3 ld(const float* p) { return f3{p[0], p[1], p[2]}; }
+RT_DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+RT_DEV f3 operator*(float s, f3 a) { return mk(a.x * s, a.y * s, a.z * s); }
+RT_DEV f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+// Vec3.h:221-232 — products summed left to right, cross as written there
+RT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV f3 cross3(f3 a, f3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_DEV float len3(f3 a) { return __fsqrt_rn(dot3(a, a)); }
+// Vec3.h:170-178 — null vectors stay null, otherwise multiply by 1/len
+RT_DEV f3 unit3(f3 a) {
+  float l = len3(a);
+  if (l == 0.f) return a;
+  float inv = 1.0f / l;
+  return mk(a.x * inv, a.y * inv, a.z * inv);
+}
+RT_DEV float dist3(f3 a, f3 b) { return len3(a - b); }
+
+// ------------------------------------------------------------------ RNG stream
+// minstd_rand0 (LightSource.h:6) + libstdc++ generate_canonical semantics
+// (SURVEY.md App. B): float draw = 1 engine call, double draw = 2 calls.
+struct Rng {
+  uint32_t s;
+  RT_DEV uint32_t next() {
+    uint64_t p = (uint64_t)s * 16807ull;                       // < 2^46
+    uint32_t x = (uint32_t)(p & 0x7fffffffull) + (uint32_t)(p >> 31);
+    if (x >= 0x7fffffffu) x -= 0x7fffffffu;                    // mod 2^31-1
+    s = x;
+    return x;
+  }
+  RT_DEV float canonF() {
+    float r = (float)(next() - 1u) / 2147483648.0f;
+    return r >= 1.0f ? 0.99999994f : r;
+  }
+  RT_DEV double canonD() {
+    const double R = 2147483646.0, R2 = 2147483646.0 * 2147483646.0;
+    double sum = (double)(next() - 1u);
+    sum += (double)(next() - 1u) * R;
+    double r = sum / R2;
+    return r >= 1.0 ? 0.99999999999999988898 : r;
+  }
+  RT_DEV float uniformF(float a, float b) { return canonF() * (b - a) + a; }
+  RT_DEV double uniformD(double a, double b) { return canonD() * (b - a) + a; }
+};
+
+// ------------------------------------------------------------------ samplers
+// RayTracer.h:109-117
+RT_DEV void jitter_sample(Rng& g, int idx, int n, float& x, float& y) {
+  int d = (int)__fsqrt_rn((float)n);
+  int j2 = idx / d, i2 = idx % d;
+  x = (float)(((double)(float)i2 + g.uniformD(0.0, 1.0)) / (double)(float)d);
+  y = (float)(((double)(float)j2 + g.uniformD(0.0, 1.0)) / (double)(float)d);
+}
+
+// Vec3.h:180-199
+RT_DEV void two_orthogonals(f3 n, f3& u, f3& v) {
+  float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+  if (ax < ay) u = (ax < az) ? mk(0.f, -n.z, n.y) : mk(-n.y, n.x, 0.f);
+  else u = (ay < az) ? mk(n.z, 0.f, -n.x) : mk(-n.y, n.x, 0.f);
+  v = cross3(n, u);
+}
+
+// RayTracer.h:95-107 with maxRayAngle = float(pi/2) (its only call value)
+RT_DEV f3 hemisphere_sample(Rng& g, f3 normal) {
+  const float maxRayAngle = 1.57079637f;
+  const double PI = 3.14159265358979323846;
+  const double hi = (double)(2 * maxRayAngle) / PI;
+  normal = unit3(normal);
+  f3 v1, v2;
+  two_orthogonals(normal, v1, v2);
+  v1 = unit3(v1);
+  v2 = unit3(v2);
+  float theta = (float)rt_asin(g.uniformD(0.0, hi));
+  float phi = (float)(2 * PI * g.uniformD(0.0, hi));
+  f3 dir = unit3(v1 * rt_cosf(phi) + v2 * rt_sinf(phi));
+  return unit3(normal * rt_cosf(theta) + dir * rt_sinf(theta));
+}
+
+// ------------------------------------------------------------------ camera / lights
+// Camera.h:27-30
+RT_DEV void camera_ray(const rt_camera& c, float u, float v, f3& o, f3& d) {
+  o = ld(c.position);
+  d = unit3(ld(c.lower_left) + u * ld(c.horizontal) + v * ld(c.vertical) - o);
+}
+
+// LightSource.h:46-49; first draw scales the horizontal axis (g++ evaluation order)
+RT_DEV f3 light_sample(Rng& g, const rt_light& l) {
+  float rh = g.uniformF(-l.side, l.side);
+  float rv = g.uniformF(-l.side, l.side);
+  return ld(l.position) + (rv * ld(l.vertical)) + (rh * ld(l.horizontal));
+}
+// LightSource.h:51-54
+RT_DEV float light_radiance(const rt_light& l, f3 p) {
+  float d = dist3(p, ld(l.position));
+  return l.intensity / (l.ac + l.al * d + l.aq * d * d);
+}
+// LightSource.h:56-59
+RT_DEV f3 light_eval(const rt_light& l, f3 p) { return l.factor * ld(l.color) * light_radiance(l, p); }
+
+// ------------------------------------------------------------------ material
+// Material.h:25-70.  Mixed precision exactly as there: D's denominator, the two
+// pow(), fmax(0,.), 4.*(n.wi)*(n.wo) and sqrt(2/pi) are double, each narrowed to
+// float where the reference assigns to a float.
+RT_DEV float g_schlick(float alpha, f3 w, f3 n) {
+  float k = (float)((double)alpha * 0x1.9884533d43651p-1 /* == sqrt(2. / M_PI) in double */);
+  float nw = dot3(n, w);
+  return nw / (nw * (1 - k) + k);
+}
+RT_DEV f3 bsdf_eval(const rt_material& m, f3 normal, f3 wi_in, f3 wo_in) {
+  const double PI = 3.14159265358979323846;
+  f3 n = unit3(normal), wi = unit3(wi_in), wo = unit3(wo_in);
+  f3 wh = unit3(wi + wo);
+  float a2 = m.alpha * m.alpha;
+  float D = (float)((double)a2 / (PI * rt_pow2(1 + (double)(a2 - 1) * rt_pow2((double)dot3(n, wh)))));
+  double c = (double)dot3(wi, wh);
+  float f5 = (float)rt_pow5(1 - (c > 0.0 ? c : 0.0));  // fmax(0, c); NaN -> 0 like fmax
+  f3 F0 = ld(m.f0);
+  f3 F = F0 + (mk(1.f, 1.f, 1.f) - F0) * f5;
+  float G = g_schlick(m.alpha, wi, n) * g_schlick(m.alpha, wo, n);
+  float denom = (float)(4. * (double)dot3(n, wi) * (double)dot3(n, wo));
+  f3 spec = D * F * G / denom;
+  f3 diffuse = ld(m.albedo) / 3.14159274f;  // albedo / float(M_PI)
+  f3 r = m.kd * diffuse + (1 - m.kd) * spec;
+  if (r.x < 0.f) r.x = 0.f;
+  if (r.y < 0.f) r.y = 0.f;
+  if (r.z < 0.f) r.z = 0.f;
+  return r;
+}
+
+// ------------------------------------------------------------------ triangle test
+// Ray.cpp:9-24 on a flattened record (p0, e1 = p1-p0, e2 = p2-p0 precomputed with
+// the same float subtraction the reference performs per test).
+RT_DEV bool tri_test(f3 o, f3 d, f3 p0, f3 e1, f3 e2, float& u, float& v, float& t) {
+  f3 pvec = cross3(d, e2);
+  float det = dot3(e1, pvec);
+  if (fabsf(det) < 0.000001f) return false;
+  float inv = 1.0f / det;
+  f3 tvec = o - p0;
+  u = dot3(tvec, pvec) * inv;
+  f3 qvec = cross3(tvec, e1);
+  v = dot3(d, qvec) * inv;
+  t = dot3(e2, qvec) * inv;
+  if (u < 0.f || u > 1.f) return false;
+  return v >= 0.f && u + v <= 1.f;
+}
+
+// Renderer.cpp:279-283; fminf/fmaxf return the non-NaN operand, so NaN -> 1
+RT_DEV float clamp01(float c) { return fmaxf(fminf(c, 1.f), 0.f); }
+
+}  // namespace rtd

@@ -1,0 +1,60 @@
+// rt_kernels.h — host<->device argument blocks and kernel launchers
+// (implemented in rt_kernels.hip, called from rt_api.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_amd.h"
+
+#define RTK_KMAX 16  // photon k-heap slots per lane (LDS budget, rt_kernels.hip)
+
+enum {
+  RTK_CNT_CLOSEST = 0,
+  RTK_CNT_SHADOW,
+  RTK_CNT_KNN,
+  RTK_CNT_NODES,
+  RTK_CNT_TRIS,
+  RTK_CNT_KD,
+  RTK_CNT_COUNT = 8
+};
+
+namespace rtk {
+
+// Device-resident flattened scene (all pointers are HBM allocations of rt_ctx).
+struct DevScene {
+  const float4* nodes;     // n_nodes x 64 B: {lo0.xyz,hi0.x}{hi0.yz,lo1.xy}{lo1.z,hi1.xyz}{c0,c1,-,-}
+  const float4* tris;      // n_tris x 48 B, BVH leaf order: {p0,e1.x}{e1.yz,e2.xy}{e2.z,id,mesh,-}
+  const float4* trisRef;   // same records in reference (mesh,tri) order (brute-force path)
+  const uint4* triShade;   // per global triangle id: {v0,v1,v2 (global vertex ids), mesh}
+  const float* vpos;       // [n_vertices][3]
+  const float* vnrm;       // [n_vertices][3]
+  const rt_material* mats; // [n_meshes]
+  const rt_light* lights;  // [n_lights]
+  const uint32_t* meshTriBegin;
+  const uint32_t* meshVtxBegin;
+  const float4* phPos;     // photons in kd-tree order: xyz + pad
+  const float4* phDir;     // income direction xyz + weight
+  uint32_t n_tris, n_nodes, n_lights, n_photons;
+  rt_camera cam;
+};
+
+struct RenderArgs {
+  const uint32_t* tiles;  // owned 8x8 tiles, x8 | y8 << 16
+  uint32_t n_tiles;
+  uint32_t width, height, spp, s0, s1, mode, max_depth, seed, k, photons_requested;
+};
+
+hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,
+                         float4* accum, unsigned long long* counters, hipStream_t stream);
+hipError_t launch_resolve(uint32_t n_pixels, uint32_t spp, const float4* accum, const float* bg, float* out,
+                          hipStream_t stream);
+hipError_t launch_trace(bool brute_force, bool any, const DevScene& S, const rt_ray* rays, uint32_t n,
+                        rt_hit* hits, unsigned long long* counters, hipStream_t stream);
+hipError_t launch_knn(const DevScene& S, const float* q, uint32_t n, uint32_t k, uint32_t* idx, float* dist,
+                      uint32_t* visited, hipStream_t stream);
+hipError_t launch_emit(const DevScene& S, uint32_t perLight, uint32_t seed, float4* outPos, float4* outDir,
+                       unsigned long long* counters, hipStream_t stream);
+hipError_t launch_unit(uint32_t which, const void* in, void* out, uint32_t n, hipStream_t stream);
+
+}  // namespace rtk

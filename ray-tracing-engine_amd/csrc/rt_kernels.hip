@@ -1,0 +1,677 @@
+// rt_kernels.hip — gfx950 kernels of the path-tracing hot path.
+//
+// Execution model (wave64, CDNA4):
+//   * one lane = one pixel; a wave owns an 8x8 pixel tile and walks the samples
+//     i = s0..s1-1 of its pixels in order, so every pixel's float sum is formed in
+//     exactly the order the reference forms it (Renderer.cpp:219-258) whatever the
+//     number of launches / GPUs the frame is split over;
+//   * BVH traversal keeps a per-lane stack in LDS laid out [level][thread]
+//     (ds_read/write_b32, lane-contiguous => bank-conflict free), node records are
+//     64 B (4 x dwordx4 per lane per step), triangle records 48 B (3 x dwordx4);
+//   * the photon k-NN keeps its k-heap in LDS ([slot][thread]) and re-uses the
+//     traversal stack region for the kd-tree's per-level split distances;
+//   * no inter-workgroup communication, no barriers: every wave is independent,
+//     counters leave through one atomic per wave.
+// Built with -ffp-contract=off (bit parity with the x86-64 oracle, no FMA).
+#include <hip/hip_runtime.h>
+
+#include "bvh_build.h"
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+using namespace rtd;
+
+namespace rtk {
+
+constexpr int BLOCK = 256;
+constexpr int STACK = rtbvh::kMaxDepth;  // 32 words per lane
+constexpr int KMAX = RTK_KMAX;           // photon heap capacity per lane
+
+struct Lds {
+  uint32_t* stack;  // [STACK][BLOCK] this thread's column: stack[level * BLOCK]
+  float* heapD;     // [KMAX][BLOCK]
+  uint32_t* heapI;  // [KMAX][BLOCK]
+};
+
+struct LaneStats {
+  uint32_t closest = 0, shadow = 0, knn = 0, nodes = 0, tris = 0, kd = 0;
+};
+
+struct HitRec {
+  float t, u, v;
+  uint32_t id, mesh;
+};
+
+RT_DEV float safe_inv(float d) {
+  // finite stand-in for 1/0 so that (lo - o) * inv never forms 0 * inf
+  return fabsf(d) < 1e-20f ? copysignf(1e20f, d) : 1.0f / d;
+}
+
+RT_DEV f3 f4xyz(const float4& a) { return mk(a.x, a.y, a.z); }
+
+// Conservative slab test of one padded child box.  Returns entry distance in tn.
+RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 inv, float tmax,
+                 float& tn) {
+  float ax = (lx - o.x) * inv.x, bx = (hx - o.x) * inv.x;
+  float ay = (ly - o.y) * inv.y, by = (hy - o.y) * inv.y;
+  float az = (lz - o.z) * inv.z, bz = (hz - o.z) * inv.z;
+  float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+  float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  tn = tnear;
+  return tnear <= fminf(tfar * 1.0000005f, tmax);
+}
+
+// RayTracer::rayTrace (RayTracer.h:27-53) through the flattened BVH.
+//   ANY = false: closest positive t; on equal t the lowest global triangle id wins
+//                (== the reference's strict '<' in mesh-then-triangle order)
+//   ANY = true : returns at the first accepted triangle with t > 0 (Renderer.cpp:54
+//                only uses the bool)
+template <bool ANY, bool STATS>
+RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
+  const f3 inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  float best = 3.402823466e+38f;  // numeric_limits<float>::max(), RayTracer.h:30
+  uint32_t bestId = 0;
+  bool found = false;
+  int sp = 0;
+  int32_t cur = 0;
+  for (;;) {
+    if (cur >= 0) {
+      const float4* n = S.nodes + 4 * (size_t)cur;
+      const float4 a = n[0], b = n[1], c = n[2];
+      const int4 ch = *reinterpret_cast<const int4*>(n + 3);
+      if (STATS) st.nodes++;
+      float t0, t1;
+      const bool h0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, best, t0);
+      const bool h1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, best, t1);
+      if (h0 && h1) {
+        const bool swap = t1 < t0;
+        stack[sp * BLOCK] = (uint32_t)(swap ? ch.x : ch.y);
+        sp++;
+        cur = swap ? ch.y : ch.x;
+        continue;
+      }
+      if (h0) {
+        cur = ch.x;
+        continue;
+      }
+      if (h1) {
+        cur = ch.y;
+        continue;
+      }
+    } else {
+      const uint32_t code = ~(uint32_t)cur;
+      const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; i++) {
+        const float4* r = S.tris + 3 * (size_t)(first + i);
+        const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+        if (STATS) st.tris++;
+        float u, v, t;
+        if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t) &&
+            t > 0.f) {
+          if (ANY) return true;
+          const uint32_t id = __float_as_uint(q2.y);
+          if (t < best || (t == best && id < bestId)) {
+            best = t, bestId = id, found = true;
+            hit.t = t, hit.u = u, hit.v = v, hit.id = id, hit.mesh = __float_as_uint(q2.z);
+          }
+        }
+      }
+    }
+    if (sp == 0) break;
+    sp--;
+    cur = (int32_t)stack[sp * BLOCK];
+  }
+  return found;
+}
+
+// The reference algorithm itself: every triangle, reference order (RayTracer.h:32-51).
+template <bool ANY, bool STATS>
+RT_DEV bool brute(const DevScene& S, f3 o, f3 d, HitRec& hit, LaneStats& st) {
+  float best = 3.402823466e+38f;
+  bool found = false;
+  for (uint32_t i = 0; i < S.n_tris; i++) {
+    const float4* r = S.trisRef + 3 * (size_t)i;  // wave-uniform address -> scalar loads
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+    float u, v, t;
+    if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t)) {
+      if (t > 0.f && t < best) {
+        if (ANY) return true;
+        best = t, found = true;
+        hit.t = t, hit.u = u, hit.v = v, hit.id = i, hit.mesh = __float_as_uint(q2.z);
+      }
+    }
+  }
+  if (STATS) st.tris += S.n_tris;
+  return found;
+}
+
+template <bool BRUTE, bool ANY, bool STATS>
+RT_DEV bool cast(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
+  if (BRUTE) return brute<ANY, STATS>(S, o, d, hit, st);
+  return traverse<ANY, STATS>(S, o, d, stack, hit, st);
+}
+
+// Renderer.cpp:274-277 dotArr: (w*a + u*b) + v*c per component
+RT_DEV f3 interp3(const float* arr, uint4 tv, float w, float u, float v) {
+  return w * ld(arr + 3 * (size_t)tv.x) + u * ld(arr + 3 * (size_t)tv.y) + v * ld(arr + 3 * (size_t)tv.z);
+}
+
+// ---------------------------------------------------------------- photon k-NN
+// kdtree::knearest (kdtree.h:87-107 recursion, :180-195 driver) on the implicit
+// median tree, restated step for step INCLUDING its quirks:
+// heap seeded with array nodes [0,k), lagging m_bestdist, squared-vs-plain prune.
+// std::make_heap/pop_heap/push_heap/sort_heap are restated from libstdc++
+// (bits/stl_heap.h: __push_heap / __adjust_heap) because result ORDER feeds a
+// float sum (Renderer.cpp:93-96).
+struct Heap {
+  float* d;     // [slot * BLOCK]
+  uint32_t* i;  // [slot * BLOCK]
+  RT_DEV float D(int s) const { return d[s * BLOCK]; }
+  RT_DEV uint32_t I(int s) const { return i[s * BLOCK]; }
+  RT_DEV void set(int s, float dv, uint32_t iv) const { d[s * BLOCK] = dv, i[s * BLOCK] = iv; }
+  RT_DEV void move(int dst, int src) const { d[dst * BLOCK] = d[src * BLOCK], i[dst * BLOCK] = i[src * BLOCK]; }
+
+  RT_DEV void push_up(int hole, int top, float vd, uint32_t vi) const {
+    int parent = (hole - 1) / 2;
+    while (hole > top && D(parent) < vd) {
+      move(hole, parent);
+      hole = parent;
+      parent = (hole - 1) / 2;
+    }
+    set(hole, vd, vi);
+  }
+  RT_DEV void adjust(int hole, int len, float vd, uint32_t vi) const {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      if (D(child) < D(child - 1)) child--;
+      move(hole, child);
+      hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+      child = 2 * (child + 1);
+      move(hole, child - 1);
+      hole = child - 1;
+    }
+    push_up(hole, top, vd, vi);
+  }
+  // std::pop_heap on [0,len): max goes to slot len-1, [0,len-1) stays a heap
+  RT_DEV void pop(int len) const {
+    if (len > 1) {
+      const float vd = D(len - 1);
+      const uint32_t vi = I(len - 1);
+      move(len - 1, 0);
+      adjust(0, len - 1, vd, vi);
+    }
+  }
+  RT_DEV void make(int len) const {
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2;; parent--) {
+      adjust(parent, len, D(parent), I(parent));
+      if (parent == 0) return;
+    }
+  }
+  RT_DEV void sort(int len) const {
+    while (len > 1) {
+      pop(len);
+      len--;
+    }
+  }
+};
+
+RT_DEV float photon_dist(const DevScene& S, uint32_t n, f3 p, float4& pos) {
+  pos = S.phPos[n];
+  return dist3(mk(pos.x, pos.y, pos.z), p);
+}
+
+// After the call the heap holds the k results in ascending distance order.
+RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* dxStack) {
+  float4 pos;
+  for (int j = 0; j < k; j++) H.set(j, photon_dist(S, (uint32_t)j, p, pos), (uint32_t)j);
+  H.make(k);
+  double bestdist = (double)H.D(0);
+  uint32_t visited = 0;
+  uint32_t pending = 0, wentLeft = 0;
+  uint32_t b = 0, e = S.n_photons;
+  int level = 0;
+  for (;;) {
+    while (b < e) {  // one kdtree::knearest(node*) activation per iteration
+      const uint32_t n = b + (e - b) / 2;
+      ++visited;
+      const float dn = photon_dist(S, n, p, pos);
+      if ((double)dn < bestdist) {
+        H.pop(k);                       // pop_heap
+        bestdist = (double)H.D(0);      // front() of the remaining k-1, then pop_back
+        H.set(k - 1, dn, n);            // push_back(*root)
+        H.push_up(k - 1, 0, dn, n);     // push_heap
+      }
+      if (bestdist == 0) break;
+      const int axis = level % 3;
+      const float pc = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
+      const float nc = axis == 0 ? pos.x : axis == 1 ? pos.y : pos.z;
+      const float dx = nc - pc;
+      dxStack[level * BLOCK] = dx;
+      const bool left = dx > 0.f;
+      pending |= 1u << level;
+      wentLeft = left ? (wentLeft | (1u << level)) : (wentLeft & ~(1u << level));
+      if (left) e = n;
+      else b = n + 1;
+      level++;
+    }
+    // unwind to the deepest activation that still owes its far-side check
+    bool resumed = false;
+    while (pending) {
+      const int L = 31 - __clz(pending);
+      pending &= ~(1u << L);
+      const double dx = (double)dxStack[L * BLOCK];
+      if (dx * dx >= bestdist) continue;  // kdtree.h:105
+      // rebuild the range of the level-L node from the path bits, take its far child
+      uint32_t rb = 0, re = S.n_photons;
+      for (int l = 0; l < L; l++) {
+        const uint32_t m = rb + (re - rb) / 2;
+        if (wentLeft & (1u << l)) re = m;
+        else rb = m + 1;
+      }
+      const uint32_t m = rb + (re - rb) / 2;
+      if (wentLeft & (1u << L)) b = m + 1, e = re, wentLeft &= ~(1u << L);
+      else b = rb, e = m, wentLeft |= (1u << L);
+      level = L + 1;
+      resumed = true;
+      break;
+    }
+    if (!resumed) break;
+  }
+  H.sort(k);
+  return visited;
+}
+
+// ---------------------------------------------------------------- shading
+// Renderer.cpp:33-61 (direct lighting with shadow rays) / :63-104 (photon map).
+template <bool BRUTE, bool PHOTON, bool STATS>
+RT_DEV f3 shade(const DevScene& S, const RenderArgs& A, Rng& g, f3 rayDir, const HitRec& h, const Lds& L,
+                f3& hitNormal, f3& point, LaneStats& st) {
+  const float w = 1.f - h.u - h.v;
+  const uint4 tv = S.triShade[h.id];
+  hitNormal = unit3(interp3(S.vnrm, tv, w, h.u, h.v));
+  point = interp3(S.vpos, tv, w, h.u, h.v);
+  const rt_material mat = S.mats[h.mesh];
+  f3 color = mk(0.f, 0.f, 0.f);
+  if (PHOTON) {
+    const Heap H{L.heapD, L.heapI};
+    const int k = (int)A.k;
+    st.knn++;
+    const uint32_t vis = knn_query(S, point, k, H, reinterpret_cast<float*>(L.stack));
+    if (STATS) st.kd += vis;
+    const float4 far = S.phPos[H.I(k - 1)];
+    const float r = dist3(mk(far.x, far.y, far.z), point);
+    const float area = (float)(3.14159265358979323846 * (double)r * (double)r);
+    f3 avg = mk(0.f, 0.f, 0.f), radiance = mk(0.f, 0.f, 0.f);
+    for (int j = 0; j < k; j++) {
+      avg = avg + f4xyz(S.phDir[H.I(j)]);
+      radiance = radiance + mk(1.f, 1.f, 1.f);
+    }
+    radiance = radiance / area;
+    radiance = radiance / (float)(int)A.photons_requested;
+    radiance = radiance * 100.f;  // Renderer.h:45
+    const f3 bsdf = bsdf_eval(mat, hitNormal, unit3(avg), -rayDir);
+    color = color + radiance * bsdf;
+  } else {
+    for (uint32_t li = 0; li < S.n_lights; li++) {
+      const rt_light Lt = S.lights[li];
+      const f3 toLight = light_sample(g, Lt) - point;
+      HitRec tmp;
+      st.shadow++;
+      if (cast<BRUTE, true, STATS>(S, point, toLight, L.stack, tmp, st)) continue;
+      const f3 bsdf = bsdf_eval(mat, hitNormal, toLight, -rayDir);
+      const f3 radiance = light_eval(Lt, point);
+      color = color + radiance * bsdf;
+    }
+  }
+  return color;
+}
+
+RT_DEV uint32_t wave_sum(uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool stats) {
+  const uint32_t c = wave_sum(st.closest), s = wave_sum(st.shadow), q = wave_sum(st.knn);
+  uint32_t n = 0, t = 0, kd = 0;
+  if (stats) n = wave_sum(st.nodes), t = wave_sum(st.tris), kd = wave_sum(st.kd);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counters[RTK_CNT_CLOSEST], (unsigned long long)c);
+    atomicAdd(&counters[RTK_CNT_SHADOW], (unsigned long long)s);
+    if (q) atomicAdd(&counters[RTK_CNT_KNN], (unsigned long long)q);
+    if (stats) {
+      atomicAdd(&counters[RTK_CNT_NODES], (unsigned long long)n);
+      atomicAdd(&counters[RTK_CNT_TRIS], (unsigned long long)t);
+      if (kd) atomicAdd(&counters[RTK_CNT_KD], (unsigned long long)kd);
+    }
+  }
+}
+
+template <bool PHOTON>
+RT_DEV Lds carve_lds(uint32_t* base) {
+  Lds L;
+  L.stack = base + threadIdx.x;
+  L.heapD = PHOTON ? reinterpret_cast<float*>(base + STACK * BLOCK) + threadIdx.x : nullptr;
+  L.heapI = PHOTON ? base + (STACK + KMAX) * BLOCK + threadIdx.x : nullptr;
+  return L;
+}
+
+// ---------------------------------------------------------------- integrate
+// Renderer::render's per-sample body (Renderer.cpp:227-258) + calculateColorRay /
+// calculateColorPath (:106-201) with the recursion unrolled to a loop.
+template <bool BRUTE, bool PHOTON, bool STATS>
+__global__ __launch_bounds__(BLOCK) void k_render(DevScene S, RenderArgs A, float4* __restrict__ accum,
+                                                  unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t lds[(STACK + (PHOTON ? 2 * KMAX : 0)) * BLOCK];
+  const Lds L = carve_lds<PHOTON>(lds);
+  const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  LaneStats st;
+  if (wave < A.n_tiles) {
+    const uint32_t tile = A.tiles[wave];
+    const uint32_t px = (tile & 0xffffu) * 8u + (lane & 7u), py = (tile >> 16) * 8u + (lane >> 3);
+    if (px < A.width && py < A.height) {
+      const uint32_t pix = py * A.width + px;
+      float4 sum = accum[pix];
+      for (uint32_t i = A.s0; i < A.s1; i++) {
+        Rng g{rt_stream_seed(A.seed, RT_STREAM_PIXEL, pix, i)};
+        float sx, sy;
+        jitter_sample(g, (int)i, (int)A.spp, sx, sy);
+        f3 o, d;
+        camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
+        f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
+        bool primary = true;
+        const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
+        for (int depth = 0; depth < nvert; depth++) {
+          HitRec h;
+          st.closest++;
+          if (!cast<BRUTE, false, STATS>(S, o, d, L.stack, h, st)) {
+            if (depth == 0) primary = false;
+            break;
+          }
+          f3 nrm, pt;
+          const f3 c = shade<BRUTE, PHOTON, STATS>(S, A, g, d, h, L, nrm, pt, st);
+          if (depth == 0) c0 = c;
+          else if (depth == 1) c1 = c;
+          else if (depth == 2) c2 = c;
+          else c3 = c;
+          if (A.mode != RT_MODE_PATH) break;
+          d = hemisphere_sample(g, nrm);  // drawn after every shaded vertex (Renderer.cpp:164)
+          o = pt;
+        }
+        // calculateColorPath returns c0 + (c1 + (c2 + (c3 + 0)))
+        const f3 total = c0 + (c1 + (c2 + (c3 + mk(0.f, 0.f, 0.f))));
+        sum.x += clamp01(total.x);
+        sum.y += clamp01(total.y);
+        sum.z += clamp01(total.z);
+        if (primary) sum.w += 1.f;
+      }
+      accum[pix] = sum;
+    }
+  }
+  flush_stats(st, counters, STATS);
+}
+
+// Renderer.cpp:262-265
+__global__ void k_resolve(uint32_t n_pixels, float spp, const float4* __restrict__ accum,
+                          const float* __restrict__ bg, float* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pixels) return;
+  const float4 a = accum[i];
+  const float miss = (float)((int)spp - (int)a.w);
+  out[3 * i + 0] = a.x / spp + bg[3 * i + 0] * miss / spp;
+  out[3 * i + 1] = a.y / spp + bg[3 * i + 1] * miss / spp;
+  out[3 * i + 2] = a.z / spp + bg[3 * i + 2] * miss / spp;
+}
+
+// ---------------------------------------------------------------- test hooks
+template <bool BRUTE, bool ANY>
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, const rt_ray* __restrict__ rays, uint32_t n,
+                                                 rt_hit* __restrict__ hits, unsigned long long* counters) {
+  __shared__ uint32_t lds[STACK * BLOCK];
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  LaneStats st;
+  if (i < n) {
+    HitRec h;
+    const f3 o = ld(rays[i].origin), d = ld(rays[i].direction);
+    const bool found = cast<BRUTE, ANY, true>(S, o, d, lds + threadIdx.x, h, st);
+    rt_hit r;
+    r.hit = found, r.mesh = 0, r.tri = 0, r.vtx[0] = r.vtx[1] = r.vtx[2] = 0, r.u = r.v = r.d = 0.f;
+    if (found && !ANY) {
+      const uint4 tv = S.triShade[h.id];
+      r.mesh = h.mesh;
+      r.tri = h.id - S.meshTriBegin[h.mesh];
+      const uint32_t vb = S.meshVtxBegin[h.mesh];
+      r.vtx[0] = tv.x - vb, r.vtx[1] = tv.y - vb, r.vtx[2] = tv.z - vb;
+      r.u = h.u, r.v = h.v, r.d = h.t;
+    }
+    hits[i] = r;
+    if (ANY) st.shadow = 1;
+    else st.closest = 1;
+  }
+  flush_stats(st, counters, true);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_knn(DevScene S, const float* __restrict__ q, uint32_t n, uint32_t k,
+                                               uint32_t* __restrict__ idx, float* __restrict__ dst,
+                                               uint32_t* __restrict__ visited) {
+  __shared__ uint32_t lds[(STACK + 2 * KMAX) * BLOCK];
+  const Lds L = carve_lds<true>(lds);
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const Heap H{L.heapD, L.heapI};
+  const uint32_t vis = knn_query(S, ld(q + 3 * (size_t)i), (int)k, H, reinterpret_cast<float*>(L.stack));
+  for (uint32_t j = 0; j < k; j++) {
+    idx[(size_t)i * k + j] = H.I((int)j);
+    dst[(size_t)i * k + j] = H.D((int)j);
+  }
+  if (visited) visited[i] = vis;
+}
+
+// PhotonMap::PhotonMap + calculatePhotonPath (PhotonMap.h:14-50,92-155), one lane
+// per emitted photon, stream key (seed, RT_STREAM_PHOTON, light*perLight + j).
+// Each emitted photon stores at most ONE particle, so slot j of the output is
+// either that particle or flagged empty: order is deterministic (compacted on host).
+template <bool BRUTE>
+__global__ __launch_bounds__(BLOCK) void k_emit(DevScene S, uint32_t perLight, uint32_t seed,
+                                                float4* __restrict__ outPos, float4* __restrict__ outDir,
+                                                unsigned long long* counters) {
+  __shared__ uint32_t lds[STACK * BLOCK];
+  uint32_t* stack = lds + threadIdx.x;
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  LaneStats st;
+  if (j < perLight * S.n_lights) {
+    const uint32_t li = j / perLight;
+    const rt_light Lt = S.lights[li];
+    Rng g{rt_stream_seed(seed, RT_STREAM_PHOTON, j, 0)};
+    const float lightPdf = 1.f / (float)S.n_lights;
+    const f3 lsNormal = ld(Lt.normal);
+    f3 o = light_sample(g, Lt);
+    f3 d = hemisphere_sample(g, lsNormal);
+    const float pdf0 = dot3(unit3(d), unit3(lsNormal));
+    float weight = light_radiance(Lt, o) / (pdf0 * lightPdf);
+    f3 ppos = mk(0.f, 0.f, 0.f), pdir = ppos;
+    bool stored = false, exitNext = false;
+    for (int depth = 0;; depth++) {
+      if (exitNext) {
+        stored = true;
+        break;
+      }
+      if (depth >= 20) break;
+      HitRec h;
+      st.closest++;
+      if (!cast<BRUTE, false, false>(S, o, d, stack, h, st)) {
+        stored = depth != 0;
+        break;
+      }
+      const float w = 1.f - h.u - h.v;
+      const uint4 tv = S.triShade[h.id];
+      const f3 nrm = unit3(interp3(S.vnrm, tv, w, h.u, h.v));
+      const f3 pt = interp3(S.vpos, tv, w, h.u, h.v);
+      ppos = pt, pdir = -d;
+      const f3 rnd = hemisphere_sample(g, nrm);
+      const f3 perfect = d - 2.f * (dot3(d, nrm)) * nrm;
+      const float bsdf = len3(bsdf_eval(S.mats[h.mesh], nrm, d, rnd));
+      const float pdf = (dot3(unit3(rnd), unit3(perfect)) + 1.f) / 2.f;
+      weight *= bsdf / pdf;
+      const float cont = fminf(weight, 1.f);
+      if (g.uniformF(0.f, 1.f) > cont) exitNext = true;
+      else weight /= cont;
+      o = pt, d = rnd;
+    }
+    outPos[j] = make_float4(ppos.x, ppos.y, ppos.z, stored ? 1.f : 0.f);
+    outDir[j] = make_float4(pdir.x, pdir.y, pdir.z, weight);
+  }
+  flush_stats(st, counters, false);
+}
+
+// Unit evaluations of the device building blocks (parity hooks, rt_test_unit).
+__global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (which) {
+    case RT_UNIT_ASIN:
+      ((double*)out)[i] = rt_asin(((const double*)in)[i]);
+      break;
+    case RT_UNIT_SINF:
+      ((float*)out)[i] = rt_sinf(((const float*)in)[i]);
+      break;
+    case RT_UNIT_COSF:
+      ((float*)out)[i] = rt_cosf(((const float*)in)[i]);
+      break;
+    case RT_UNIT_STREAM_SEED: {
+      const uint32_t* a = (const uint32_t*)in + 4 * (size_t)i;
+      ((uint32_t*)out)[i] = rt_stream_seed(a[0], a[1], a[2], a[3]);
+      break;
+    }
+    case RT_UNIT_TRIANGLE: {  // in: p0 p1 p2 o d (15 floats); out: hit u v t (4 floats)
+      const float* a = (const float*)in + 15 * (size_t)i;
+      float* o = (float*)out + 4 * (size_t)i;
+      const f3 p0 = ld(a), p1 = ld(a + 3), p2 = ld(a + 6);
+      float u = o[1], v = o[2], t = o[3];  // outputs may stay unwritten (Ray.cpp:14)
+      const bool hit = tri_test(ld(a + 9), ld(a + 12), p0, p1 - p0, p2 - p0, u, v, t);
+      o[0] = hit ? 1.f : 0.f, o[1] = u, o[2] = v, o[3] = t;
+      break;
+    }
+    case RT_UNIT_BSDF: {  // in: kd alpha albedo3 f03 n3 wi3 wo3 (17 floats); out: 3 floats
+      const float* a = (const float*)in + 17 * (size_t)i;
+      rt_material m;
+      m.kd = a[0], m.alpha = a[1];
+      for (int c = 0; c < 3; c++) m.albedo[c] = a[2 + c], m.f0[c] = a[5 + c];
+      const f3 r = bsdf_eval(m, ld(a + 8), ld(a + 11), ld(a + 14));
+      float* o = (float*)out + 3 * (size_t)i;
+      o[0] = r.x, o[1] = r.y, o[2] = r.z;
+      break;
+    }
+    case RT_UNIT_RAY_AT: {  // in: camera(12) u v (14 floats); out: o3 d3
+      const float* a = (const float*)in + 14 * (size_t)i;
+      rt_camera c;
+      for (int k = 0; k < 3; k++)
+        c.position[k] = a[k], c.lower_left[k] = a[3 + k], c.horizontal[k] = a[6 + k], c.vertical[k] = a[9 + k];
+      f3 o, d;
+      camera_ray(c, a[12], a[13], o, d);
+      float* q = (float*)out + 6 * (size_t)i;
+      q[0] = o.x, q[1] = o.y, q[2] = o.z, q[3] = d.x, q[4] = d.y, q[5] = d.z;
+      break;
+    }
+    case RT_UNIT_LIGHT_EVAL: {  // in: rt_light(21 floats) p3; out: 3
+      const float* a = (const float*)in + 24 * (size_t)i;
+      rt_light l;
+      memcpy(&l, a, sizeof(rt_light));
+      const f3 r = light_eval(l, ld(a + 21));
+      float* o = (float*)out + 3 * (size_t)i;
+      o[0] = r.x, o[1] = r.y, o[2] = r.z;
+      break;
+    }
+    case RT_UNIT_SAMPLERS: {
+      // in (28 words): state, idx, n, pad, normal3, pad, rt_light(21 floats).
+      // out (12 words): jitter x y, hemisphere dir3, light sample3, end state, pad3.
+      // Draw order: jitter, hemisphere, light — each from the running state.
+      const uint32_t* a = (const uint32_t*)in + 28 * (size_t)i;
+      const float* af = (const float*)a;
+      Rng g{a[0]};
+      float* o = (float*)out + 12 * (size_t)i;
+      jitter_sample(g, (int)a[1], (int)a[2], o[0], o[1]);
+      const f3 h = hemisphere_sample(g, ld(af + 4));
+      rt_light l;
+      memcpy(&l, af + 7, sizeof(rt_light));
+      const f3 p = light_sample(g, l);
+      o[2] = h.x, o[3] = h.y, o[4] = h.z, o[5] = p.x, o[6] = p.y, o[7] = p.z;
+      ((uint32_t*)o)[8] = g.s;
+      o[9] = o[10] = o[11] = 0.f;
+      break;
+    }
+    default:
+      break;
+  }
+}
+
+// ---------------------------------------------------------------- launchers
+template <bool BRUTE, bool PHOTON>
+static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
+                                 unsigned long long* counters, hipStream_t stream) {
+  const uint32_t blocks = (A.n_tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
+  if (blocks == 0) return hipSuccess;
+  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true>), dim3(blocks), dim3(BLOCK), 0, stream, S, A, accum, counters);
+  else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false>), dim3(blocks), dim3(BLOCK), 0, stream, S, A, accum, counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,
+                         float4* accum, unsigned long long* counters, hipStream_t stream) {
+  if (brute_force) return photon ? launch_render2<true, true>(stats, S, A, accum, counters, stream)
+                                 : launch_render2<true, false>(stats, S, A, accum, counters, stream);
+  return photon ? launch_render2<false, true>(stats, S, A, accum, counters, stream)
+                : launch_render2<false, false>(stats, S, A, accum, counters, stream);
+}
+
+hipError_t launch_resolve(uint32_t n_pixels, uint32_t spp, const float4* accum, const float* bg, float* out,
+                          hipStream_t stream) {
+  if (n_pixels == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, n_pixels, (float)spp, accum,
+                     bg, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_trace(bool brute_force, bool any, const DevScene& S, const rt_ray* rays, uint32_t n,
+                        rt_hit* hits, unsigned long long* counters, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
+  if (brute_force) {
+    if (any) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, S, rays, n, hits, counters);
+    else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, stream, S, rays, n, hits, counters);
+  } else {
+    if (any) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, stream, S, rays, n, hits, counters);
+    else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, stream, S, rays, n, hits, counters);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_knn(const DevScene& S, const float* q, uint32_t n, uint32_t k, uint32_t* idx, float* dist,
+                      uint32_t* visited, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_knn, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, S, q, n, k, idx, dist, visited);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit(const DevScene& S, uint32_t perLight, uint32_t seed, float4* outPos, float4* outDir,
+                       unsigned long long* counters, hipStream_t stream) {
+  const uint32_t n = perLight * S.n_lights;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_emit<false>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, S, perLight, seed,
+                     outPos, outDir, counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_unit(uint32_t which, const void* in, void* out, uint32_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_unit, dim3((n + 255) / 256), dim3(256), 0, stream, which, in, out, n);
+  return hipGetLastError();
+}
+
+}  // namespace rtk
