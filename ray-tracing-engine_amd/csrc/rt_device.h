@@ -36,7 +36,9 @@ RT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_DEV f3 cross3(f3 a, f3 b) {
   return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-RT_DEV float len3(f3 a) { return __fsqrt_rn(dot3(a, a)); }
+// NB: __fsqrt_rn() lowers to a bare v_sqrt_f32 (1 ulp) on gfx950; sqrtf / __builtin_sqrtf
+// get the correctly rounded expansion (v_sqrt_f32 + residual fix-up).
+RT_DEV float len3(f3 a) { return __builtin_sqrtf(dot3(a, a)); }
 // Vec3.h:170-178 — null vectors stay null, otherwise multiply by 1/len
 RT_DEV f3 unit3(f3 a) {
   float l = len3(a);
@@ -76,7 +78,7 @@ struct Rng {
 // ------------------------------------------------------------------ samplers
 // RayTracer.h:109-117
 RT_DEV void jitter_sample(Rng& g, int idx, int n, float& x, float& y) {
-  int d = (int)__fsqrt_rn((float)n);
+  int d = (int)__builtin_sqrtf((float)n);
   int j2 = idx / d, i2 = idx % d;
   x = (float)(((double)(float)i2 + g.uniformD(0.0, 1.0)) / (double)(float)d);
   y = (float)(((double)(float)j2 + g.uniformD(0.0, 1.0)) / (double)(float)d);

@@ -1,0 +1,70 @@
+"""The C-ABI libraries load on a machine without a GPU and export every symbol
+include/rt_amd.h and include/rt_host.h declare; compute entry points refuse to
+run (no CPU fallback) when no gfx950 device is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import pyrt
+
+
+def _declared(header):
+    txt = open(os.path.join(pyrt.ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_amd_symbols_match_header():
+    decl = _declared("rt_amd.h")
+    assert decl == sorted(pyrt.AMD_SYMBOLS)
+    L = pyrt.amd()
+    for s in decl:
+        assert hasattr(L, s), s
+    assert L.rt_abi_version() == 1
+
+
+def test_host_symbols_match_header():
+    decl = [s for s in _declared("rt_host.h")]
+    assert decl == sorted(pyrt.HOST_SYMBOLS)
+    L = pyrt.host()
+    for s in decl:
+        assert hasattr(L, s), s
+
+
+def test_struct_sizes():
+    assert C.sizeof(pyrt.Material) == 32 and C.sizeof(pyrt.Light) == 84 and C.sizeof(pyrt.Camera) == 48
+    assert C.sizeof(pyrt.Params) == 96 and C.sizeof(pyrt.Stats) == 96
+    assert pyrt.RAY_DTYPE.itemsize == 24 and pyrt.HIT_DTYPE.itemsize == 36
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.device_count() > 0
+
+
+@pytest.mark.skipif(_has_gpu(), reason="a GPU is present")
+def test_no_device_is_a_loud_error_not_a_fallback():
+    s = pyrt.Scene("cubes", 32, 32)
+    with pytest.raises(pyrt.RtError) as e:
+        pyrt.Context(s)
+    assert e.value.code == 2 and "no CPU path" in str(e.value)
+    import numpy as np
+    with pytest.raises(pyrt.RtError):
+        pyrt.unit(pyrt.UNIT_SINF, np.zeros(4, np.float32))
+
+
+def test_scene_rejects_unknown_kind_and_missing_mesh(tmp_path):
+    with pytest.raises(pyrt.RtError):
+        pyrt.Scene("nope", 8, 8)
+    with pytest.raises(pyrt.RtError):
+        pyrt.Scene("cubes", 8, 8, mesh_dir=str(tmp_path))
+
+
+def test_stress_scene_shape():
+    s = pyrt.Scene("stress", 64, 64)
+    assert s.desc.n_triangles == 6 + 2 + 2 + 1000008 + 12
+    a = s.arrays()
+    lo, hi = a["pos"][a["vtx_begin"][3]:a["vtx_begin"][4]].min(0), a["pos"][a["vtx_begin"][3]:a["vtx_begin"][4]].max(0)
+    assert (lo > [-1.41, -0.96, -1.41]).all() and (hi < [1.41, 1.41, 1.01]).all()

@@ -1,0 +1,376 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle (oracle/liboracle.so) on the same seeded inputs and against the golden
+vectors produced by the real reference.  Bit-exact unless a tolerance is stated."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import pyrt
+
+pytestmark = pytest.mark.gpu
+
+
+def f32(u):
+    return np.array(u, dtype=np.uint32).view(np.float32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def cubes():
+    s = pyrt.Scene("cubes", 256, 256)
+    return s, pyrt.Context(s)
+
+
+@pytest.fixture(scope="module")
+def lowres():
+    s = pyrt.Scene("lowres", 256, 256)
+    return s, pyrt.Context(s)
+
+
+# ------------------------------------------------------------------ building blocks
+def test_detmath_device_equals_host():
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 1.0000000279, 200000), [0.0, 1.0, 0.5, 0.975, 1.0000000278, 1e-9, 0.4999999]])
+    got = pyrt.unit(pyrt.UNIT_ASIN, x)[:, 0]
+    ref = np.array([orc.lib().orc_det_asin(float(v)) for v in x[:20000]] )
+    assert np.array_equal(got[:20000].view(np.uint64), ref.view(np.uint64))
+    # nan for |x|>1 on both
+    assert np.isnan(got[-3]) and np.isnan(orc.lib().orc_det_asin(1.0000000278))
+    a = np.concatenate([rng.uniform(0, 6.2831860, 200000), [0.0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi]]).astype(np.float32)
+    for which, fn in ((pyrt.UNIT_SINF, orc.lib().orc_det_sinf), (pyrt.UNIT_COSF, orc.lib().orc_det_cosf)):
+        got = pyrt.unit(which, a)[:, 0]
+        ref = np.array([fn(float(v)) for v in a[:20000]], np.float32)
+        assert np.array_equal(bits(got[:20000]), bits(ref))
+        # and close to libm (not bit-equal: see tests/test_oracle_images.py)
+        lib = np.sin(a.astype(np.float64)) if which == pyrt.UNIT_SINF else np.cos(a.astype(np.float64))
+        assert np.abs(got - lib).max() < 1.2e-7
+    k = rng.integers(0, 2**32, (5000, 4), dtype=np.uint64).astype(np.uint32)
+    k[:, 1] &= 1
+    got = pyrt.unit(pyrt.UNIT_STREAM_SEED, k)[:, 0]
+    ref = np.array([orc.lib().orc_stream_seed(*map(int, r)) for r in k], np.uint32)
+    assert np.array_equal(got, ref) and got.min() >= 1 and got.max() <= 2147483646
+
+
+def test_triangle_intersect_golden(golden):
+    v = np.array(golden["vectors"]["triangleIntersect"], np.uint32).reshape(-1, 19)
+    init = np.full((len(v), 4), -7.0, np.float32)
+    out = pyrt.unit(pyrt.UNIT_TRIANGLE, f32(v[:, :15]), init)
+    assert np.array_equal(out[:, 0].astype(np.uint32), v[:, 15])
+    assert np.array_equal(bits(out[:, 1:4]), v[:, 16:19])
+
+
+def test_bsdf_golden(golden):
+    """The golden values were computed by the reference with libm pow(); the device
+    uses x*x and (x*x)*(x*x)*x (rt_pixelmode.h).  Both are within 1 ulp in double,
+    which survives the narrowing to float with probability ~1e-8: expect bit
+    equality on all 300 vectors."""
+    v = np.array(golden["vectors"]["bsdf"], np.uint32).reshape(-1, 20)
+    inp = np.concatenate([v[:, 9:17], v[:, 0:9]], axis=1)  # kd alpha albedo f0 | n wi wo
+    out = pyrt.unit(pyrt.UNIT_BSDF, f32(inp))
+    assert np.array_equal(bits(out), v[:, 17:20])
+
+
+def test_ray_at_and_light_golden(golden, cubes):
+    s, _ = cubes
+    V = golden["vectors"]
+    v = np.array(V["rayAt"], np.uint32).reshape(-1, 8)
+    cam = np.frombuffer(bytes(s.desc.camera), np.uint32)
+    inp = np.concatenate([np.tile(cam, (len(v), 1)), v[:, :2]], axis=1)
+    out = pyrt.unit(pyrt.UNIT_RAY_AT, f32(inp))
+    assert np.array_equal(bits(out), v[:, 2:8])
+    lv = np.array(V["evaluateLight"], np.uint32).reshape(3, 20, 6)
+    lights = np.frombuffer(C.string_at(s.desc.lights, 84 * 3), np.uint32).reshape(3, 21)
+    for li in range(3):
+        inp = np.concatenate([np.tile(lights[li], (20, 1)), lv[li, :, :3]], axis=1)
+        out = pyrt.unit(pyrt.UNIT_LIGHT_EVAL, f32(inp))
+        assert np.array_equal(bits(out), lv[li, :, 3:6])
+
+
+def test_samplers_against_oracle(cubes):
+    s, _ = cubes
+    rng = np.random.default_rng(11)
+    n = 4000
+    lights = np.frombuffer(C.string_at(s.desc.lights, 84 * 3), np.uint32).reshape(3, 21)
+    inp = np.zeros((n, 28), np.uint32)
+    inp[:, 0] = rng.integers(1, 2147483646, n)
+    N = rng.choice([1, 2, 3, 4, 8, 16, 128], n)
+    inp[:, 2] = N
+    inp[:, 1] = rng.integers(0, 1 << 30, n) % N
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm[::7] = [0, 1, 0]
+    nrm[1::7] = [0, 0, -1]
+    inp[:, 4:7] = bits(nrm)
+    li = rng.integers(0, 3, n)
+    inp[:, 7:28] = lights[li]
+    out = pyrt.unit(pyrt.UNIT_SAMPLERS, inp)
+    xy, hs, ls = np.zeros(2, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+    L = orc.lib()
+    for i in range(n):
+        st = C.c_uint32(int(inp[i, 0]))
+        L.orc_jitter(C.byref(st), int(inp[i, 1]), int(inp[i, 2]), orc._p(xy))
+        nn = nrm[i].copy()
+        L.orc_hsphere(C.byref(st), orc.MATH_DET, orc._p(nn), orc._p(hs))
+        L.orc_rand_area(C.byref(st), C.byref(s.desc.lights[int(li[i])]), orc._p(ls))
+        assert np.array_equal(out[i, 0:2], bits(xy)), i
+        assert np.array_equal(out[i, 2:5], bits(hs)), i
+        assert np.array_equal(out[i, 5:8], bits(ls)), i
+        assert out[i, 8] == st.value
+
+
+def test_jitter_and_light_sample_golden(golden, cubes):
+    """Sequences drawn from a fresh seed-1 engine by the reference itself."""
+    s, _ = cubes
+    V = golden["vectors"]
+    lights = np.frombuffer(C.string_at(s.desc.lights, 84 * 3), np.uint32).reshape(3, 21)
+    state = 1
+    for N, i, bx, by in np.array(V["jitterSample_seq"], np.uint32).reshape(-1, 4):
+        inp = np.zeros((1, 28), np.uint32)
+        inp[0, 0], inp[0, 1], inp[0, 2] = state, i, N
+        inp[0, 4:7] = bits(np.array([0, 1, 0], np.float32))
+        inp[0, 7:28] = lights[0]
+        out = pyrt.unit(pyrt.UNIT_SAMPLERS, inp)[0]
+        assert (out[0], out[1]) == (bx, by)
+        st = C.c_uint32(state)  # advance by the 4 engine calls of jitterSample only
+        for _ in range(4):
+            orc.lib().orc_engine_next(C.byref(st))
+        state = st.value
+
+
+# ------------------------------------------------------------------ closest hit / any hit
+def _ray_batch(scene, n, seed):
+    """Camera rays, rays leaving surface points exactly (no epsilon), random rays,
+    axis-parallel rays (zero direction components) and a NaN ray."""
+    rng = np.random.default_rng(seed)
+    a = scene.arrays()
+    rays = np.zeros(n, pyrt.RAY_DTYPE)
+    cam = a["camera"]
+    u, v = rng.random(n, np.float32), rng.random(n, np.float32)
+    d = cam[1] + u[:, None] * cam[2] + v[:, None] * cam[3] - cam[0]
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["origin"], rays["direction"] = cam[0], d.astype(np.float32)
+    # surface starts: barycentric points of random triangles
+    m = n // 2
+    t = rng.integers(0, len(a["tri"]), m)
+    b = rng.random((m, 2), np.float32)
+    b[b.sum(1) > 1] = 1 - b[b.sum(1) > 1]
+    P = a["pos"][a["tri"][t]]
+    w = (1 - b[:, 0] - b[:, 1]).astype(np.float32)
+    pts = w[:, None] * P[:, 0] + b[:, 0:1] * P[:, 1] + b[:, 1:2] * P[:, 2]
+    rays["origin"][:m] = pts.astype(np.float32)
+    dirs = rng.normal(size=(m, 3)).astype(np.float32)
+    dirs[::3] /= np.linalg.norm(dirs[::3], axis=1, keepdims=True)
+    dirs[1::5] = (np.array([0.0, -0.3, 1.1], np.float32) - pts[1::5]).astype(np.float32)  # towards light 2
+    rays["direction"][:m] = dirs
+    q = n // 16
+    rays["direction"][m:m + q] = rng.choice(np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 1, 1], [-1, 0, 1]], np.float32), q)
+    rays["origin"][m:m + q] = rng.uniform(-1.4, 1.4, (q, 3)).astype(np.float32)
+    rays["direction"][m + q] = np.nan
+    return rays
+
+
+@pytest.mark.parametrize("which", ["cubes", "lowres"])
+def test_trace_golden(golden, which, cubes, lowres):
+    s, ctx = cubes if which == "cubes" else lowres
+    v = np.array(golden["vectors"]["rayTrace_" + which], np.uint32).reshape(-1, 14)
+    rays = np.zeros(len(v), pyrt.RAY_DTYPE)
+    rays["origin"], rays["direction"] = f32(v[:, 0:3]), f32(v[:, 3:6])
+    for accel in (pyrt.ACCEL_BRUTE, pyrt.ACCEL_BVH):
+        h = ctx.trace(rays, accel)
+        assert np.array_equal(h["hit"].astype(np.uint32), v[:, 6])
+        m = v[:, 6] == 1
+        assert np.array_equal(h["mesh"][m], v[m, 7]) and np.array_equal(h["vtx"][m], v[m, 8:11])
+        assert np.array_equal(bits(h["u"][m]), v[m, 11]) and np.array_equal(bits(h["v"][m]), v[m, 12])
+        assert np.array_equal(bits(h["d"][m]), v[m, 13])
+        a = ctx.trace(rays, accel, pyrt.TRACE_ANY)
+        assert np.array_equal(a["hit"].astype(np.uint32), v[:, 6])
+
+
+@pytest.mark.parametrize("which,n", [("cubes", 200000), ("lowres", 40000)])
+def test_trace_bvh_equals_brute_equals_oracle(which, n, cubes, lowres):
+    s, ctx = cubes if which == "cubes" else lowres
+    rays = _ray_batch(s, n, 1234)
+    ref = orc.trace(s, rays)
+    for accel in (pyrt.ACCEL_BRUTE, pyrt.ACCEL_BVH):
+        h = ctx.trace(rays, accel)
+        assert np.array_equal(h.view(np.uint8), ref.view(np.uint8)), accel  # every field, every bit
+        a = ctx.trace(rays, accel, pyrt.TRACE_ANY)
+        assert np.array_equal(a["hit"], ref["hit"])
+    assert 0.3 < ref["hit"].mean() < 1.0
+
+
+def test_trace_large_bvh_vs_brute_on_gpu(lowres):
+    """2M rays: the BVH must agree with the exhaustive loop on every field (GPU vs GPU,
+    the oracle is too slow here)."""
+    s, ctx = lowres
+    rays = _ray_batch(s, 2_000_000, 99)
+    a = ctx.trace(rays, pyrt.ACCEL_BRUTE)
+    b = ctx.trace(rays, pyrt.ACCEL_BVH)
+    assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_bvh_structure(lowres):
+    s, ctx = lowres
+    bi = ctx.bvh_info()
+    nodes, tris = ctx.bvh_export()
+    assert bi.n_tri_records == s.desc.n_triangles and bi.max_depth < 32 and bi.pad > 0
+    ids = tris[:, 9]
+    assert sorted(ids.tolist()) == list(range(s.desc.n_triangles))  # every triangle exactly once
+    seen = np.zeros(bi.n_tri_records, bool)
+    lo = nodes[:, [0, 1, 2, 6, 7, 8]].view(np.float32).reshape(-1, 2, 3)
+    hi = nodes[:, [3, 4, 5, 9, 10, 11]].view(np.float32).reshape(-1, 2, 3)
+    tf = tris.view(np.float32)
+    for ni in range(bi.n_nodes):
+        for c in range(2):
+            ch = int(nodes[ni, 12 + c].view(np.int32)) if False else int(np.int32(nodes[ni, 12 + c]))
+            if ch < 0:
+                code = (~ch) & 0xFFFFFFFF
+                first, cnt = code >> 3, (code & 7) + 1
+                assert cnt <= bi.leaf_max and not seen[first:first + cnt].any()
+                seen[first:first + cnt] = True
+                p0 = tf[first:first + cnt, 0:3]
+                verts = np.stack([p0, p0 + tf[first:first + cnt, 3:6], p0 + tf[first:first + cnt, 6:9]], 1)
+                assert (verts >= lo[ni, c] - 1e-6).all() and (verts <= hi[ni, c] + 1e-6).all()
+            else:
+                assert 0 < ch < bi.n_nodes
+                assert (lo[ch] >= lo[ni, c] - 1e-6).all() and (hi[ch] <= hi[ni, c] + 1e-6).all()
+    assert seen.all()
+
+
+# ------------------------------------------------------------------ whole frames
+CASES = [("cubes", 64, 64, 8, pyrt.MODE_PATH), ("cubes", 64, 64, 4, pyrt.MODE_RAY), ("cubes", 96, 64, 3, pyrt.MODE_PATH),
+         ("cubes", 37, 29, 5, pyrt.MODE_PATH), ("lowres", 40, 40, 4, pyrt.MODE_PATH), ("lowres", 32, 32, 2, pyrt.MODE_RAY)]
+
+
+@pytest.mark.parametrize("kind,w,h,spp,mode", CASES)
+def test_frame_bit_exact_vs_oracle(kind, w, h, spp, mode):
+    s = pyrt.Scene(kind, w, h)
+    ctx = pyrt.Context(s)
+    bg = pyrt.background(w, h)
+    p = pyrt.make_params(w, h, spp, mode=mode, seed=17, collect_stats=1)
+    ref_out, ref_acc, ref_st = orc.render(s, p, math_mode=orc.MATH_DET, bg=bg)
+    for accel in (pyrt.ACCEL_BVH, pyrt.ACCEL_BRUTE):
+        p.accel = accel
+        out, acc, st = ctx.render(p, bg)
+        assert np.array_equal(bits(acc), bits(ref_acc)), (kind, accel)
+        assert np.array_equal(bits(out), bits(ref_out))
+        assert (st.rays_closest, st.rays_shadow, st.samples) == (ref_st.rays_closest, ref_st.rays_shadow, w * h * spp)
+        if accel == pyrt.ACCEL_BRUTE:
+            # closest-hit casts test every triangle like the reference; the any-hit
+            # (shadow) loop leaves at its first accepted triangle, the reference's does not
+            T = s.desc.n_triangles
+            assert st.rays_closest * T <= st.tris_tested <= ref_st.tris_tested == (st.rays_closest + st.rays_shadow) * T
+    assert orc.ppm_md5(out) == orc.ppm_md5(ref_out)
+    ctx.close()
+
+
+def test_frame_is_deterministic_and_split_invariant():
+    """Same frame rendered (a) twice, (b) as 3 sample ranges, (c) as 2 x 3 tile shards
+    summed afterwards: all bit-identical (the per-pixel float sum order never changes)."""
+    w, h, spp = 128, 96, 6
+    s = pyrt.Scene("lowres", w, h)
+    ctx = pyrt.Context(s)
+    p = pyrt.make_params(w, h, spp, seed=5)
+    _, full, _ = ctx.render(p)
+    _, again, _ = ctx.render(p)
+    assert np.array_equal(bits(full), bits(again))
+    import torch
+    acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    for b, c in ((0, 1), (1, 3), (4, 2)):
+        q = pyrt.make_params(w, h, spp, seed=5, spp_begin=b, spp_count=c)
+        ctx.render_device(q, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(full))
+    for world, tile in ((2, 8), (3, 16), (5, 32)):
+        total = np.zeros((h, w, 4), np.float32)
+        owned = np.zeros((h, w), np.int32)
+        for r in range(world):
+            q = pyrt.make_params(w, h, spp, seed=5, rank=r, world=world, tile=tile)
+            _, part, st = ctx.render(q)
+            owned += (part[..., :3].sum(-1) + part[..., 3] > 0)
+            total += part  # adding zeros is exact
+        assert np.array_equal(bits(total), bits(full)), (world, tile)
+        assert owned.max() <= 1
+    ctx.close()
+
+
+def test_parameter_validation(cubes):
+    s, ctx = cubes
+    for kw, code in ((dict(rng_mode=pyrt.RNG_LEGACY), 4), (dict(max_depth=0), 4), (dict(max_depth=5), 4),
+                     (dict(use_photons=1, k=5, photons_requested=100), 5), (dict(rank=2, world=2), 1),
+                     (dict(tile=12), 1), (dict(spp_begin=3, spp_count=4), 1)):
+        with pytest.raises(pyrt.RtError) as e:
+            ctx.render(pyrt.make_params(16, 16, 4, **kw))
+        assert e.value.code == code, kw
+    with pytest.raises(pyrt.RtError):
+        ctx.render(pyrt.make_params(0, 16, 4))
+    with pytest.raises(pyrt.RtError) as e:
+        ctx.knn(np.zeros((1, 3), np.float32), 3)
+    assert e.value.code == 5 and "tree is empty" in str(e.value)
+
+
+# ------------------------------------------------------------------ photon map
+def test_photon_emission_bit_exact_vs_oracle(cubes):
+    s, ctx = cubes
+    pos, dir_, w = ctx.emit_photons(6000, seed=9)
+    ref, _, _ = orc.emit_photons(s, 6000, pyrt.RNG_PIXEL, seed=9, math_mode=orc.MATH_DET)
+    assert len(pos) == len(ref) > 3000
+    assert np.array_equal(bits(pos), bits(ref[:, 0:3])) and np.array_equal(bits(dir_), bits(ref[:, 3:6]))
+    assert np.array_equal(bits(w), bits(ref[:, 6]))
+
+
+def test_knn_golden_and_oracle(golden, cubes):
+    """k-NN on the REFERENCE's photon list and kd order (golden), results as the
+    reference's kdtree::knearest returned them; then a big random query set vs the oracle."""
+    s, ctx = cubes
+    V = golden["vectors"]
+    ph = np.array(V["photons_cubes_3000"], np.uint32).view(np.float32).reshape(-1, 7)
+    kp, kd_, kw = pyrt.kd_order(ph[:, 0:3], ph[:, 3:6], ph[:, 6])
+    assert np.array_equal(bits(kp), np.array(V["kdtree_order_pos"], np.uint32).reshape(-1, 3))
+    ctx.set_photons(kp, kd_)
+    q = np.array(V["knearest"], np.uint32)
+    i = 0
+    by_k = {}
+    while i < len(q):
+        k = int(q[i + 3])
+        by_k.setdefault(k, []).append((f32(q[i:i + 3]), int(q[i + 4]), q[i + 5:i + 5 + 6 * k].reshape(k, 6)))
+        i += 5 + 6 * k
+    for k, items in by_k.items():
+        idx, dist, vis = ctx.knn(np.stack([it[0] for it in items]), k)
+        for j, (_, visited, res) in enumerate(items):
+            assert vis[j] == visited
+            assert np.array_equal(bits(kp[idx[j]]), res[:, 0:3]) and np.array_equal(bits(kd_[idx[j]]), res[:, 3:6])
+    rng = np.random.default_rng(3)
+    qs = rng.uniform([-1.5, -1, -1.5], [1.5, 1.5, 1.5], (50000, 3)).astype(np.float32)
+    qs[::4] = kp[rng.integers(0, len(kp), len(qs[::4]))] + rng.normal(0, 0.02, (len(qs[::4]), 3)).astype(np.float32)
+    qs[7] = kp[11]  # exact hit
+    kd7 = np.concatenate([kp, kd_, kw[:, None]], 1)
+    for k in (1, 2, 5, 10, 16):
+        idx, dist, vis = ctx.knn(qs, k)
+        ri, rd, rv = orc.knn(kd7, qs, k)
+        assert np.array_equal(idx, ri) and np.array_equal(bits(dist), bits(rd)) and np.array_equal(vis, rv)
+    ctx.set_photons(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+
+
+@pytest.mark.parametrize("kind,w,h,spp,mode,nph,k", [("cubes", 64, 64, 3, pyrt.MODE_RAY, 5000, 10),
+                                                     ("cubes", 48, 40, 2, pyrt.MODE_PATH, 3000, 5),
+                                                     ("lowres", 32, 32, 2, pyrt.MODE_RAY, 3000, 10)])
+def test_photon_frame_bit_exact_vs_oracle(kind, w, h, spp, mode, nph, k):
+    s = pyrt.Scene(kind, w, h)
+    ctx = pyrt.Context(s)
+    pos, dir_, wt = ctx.emit_photons(nph, seed=2)
+    kp, kd_, kw = pyrt.kd_order(pos, dir_, wt)
+    ctx.set_photons(kp, kd_)
+    bg = pyrt.background(w, h)
+    p = pyrt.make_params(w, h, spp, mode=mode, seed=23, use_photons=1, k=k, photons_requested=nph, collect_stats=1)
+    out, acc, st = ctx.render(p, bg)
+    ext = np.concatenate([kp, kd_, kw[:, None]], 1)
+    ref_out, ref_acc, ref_st = orc.render(s, p, math_mode=orc.MATH_DET, bg=bg, ext_photons=ext)
+    assert np.array_equal(bits(acc), bits(ref_acc))
+    assert np.array_equal(bits(out), bits(ref_out))
+    assert (st.knn_queries, st.kd_visited, st.rays_shadow) == (ref_st.knn_queries, ref_st.kd_visited, 0)
+    ctx.close()
