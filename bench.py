@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X path-tracing hot path.
+
+Workload (BASELINE.json configs[1]): 1024x1024, -m 1 (path), -N 128 spp, Cornell
+box with meshes/example_low_res.off in slot 3 (1,222 triangles), pixel-RNG seed 1.
+A "step" is one whole frame: zero the accumulator, integrate every sample of every
+owned pixel (one HIP launch per rank), reduce over ranks (N>1), resolve on rank 0.
+Metric: Mrays/s = (closest-hit + shadow rays actually cast) / wall time, whole job.
+
+  python bench.py --gpus N --steps K --warmup W
+N>1 is launched by torch.distributed.run, one rank per GPU (RCCL); the frame is
+tile-sharded over ranks, i.e. total work is fixed: "scaling": "strong".
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ray-tracing-engine_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (scene, width, height, spp, mode, photons, k)
+    "C2": ("lowres", 1024, 1024, 128, 1, 0, 0),
+    "C1": ("cubes", 256, 256, 8, 1, 0, 0),
+    "C3": ("cubes", 1024, 1024, 16, 0, 50000, 10),
+    "C4": ("hires", 2048, 2048, 512, 1, 0, 0),
+    "C5": ("stress", 1024, 1024, 256, 1, 0, 0),
+}
+
+
+def cpu_baseline(scene_kind, mode, spp_full):
+    """The REAL reference (oracle/_ref/ref_harness = reference sources + our driver)
+    timed single-threaded on a bounded sample of the same workload: same scene, same
+    mode, 8 spp at 56x56 (~25k samples; brute force costs ~0.3 ms per sample on the
+    low-res scene).  Rays are counted by the oracle's legacy mode on the same input
+    (its image is byte-identical to the reference's, so the counts are the reference's)."""
+    import orc
+    import pyrt
+    w = h = 56
+    n = 8
+    meshes = pyrt.MESH_DIR
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    scene = pyrt.Scene(scene_kind, w, h)
+    p = pyrt.make_params(w, h, n, mode=mode, rng_mode=pyrt.RNG_LEGACY)
+    t0 = time.perf_counter()
+    _, _, st = orc.render(scene, p, math_mode=orc.MATH_LIBM)
+    t_port = time.perf_counter() - t0
+    rays = st.rays_closest + st.rays_shadow
+    sample = "%s scene, %dx%d, -m %d -N %d, legacy RNG seed 1 (%d rays)" % (scene_kind, w, h, mode, n, rays)
+    if os.path.exists(harness):
+        with tempfile.TemporaryDirectory() as tmp:
+            r = subprocess.run([harness, "time", meshes, scene_kind, str(w), str(h), str(mode), str(n), "0", "0"],
+                               cwd=tmp, capture_output=True, text=True, check=True)
+        secs = json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
+        return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference", "sample": sample,
+                "seconds": secs, "port_value": rays / t_port / 1e6}
+    return {"value": rays / t_port / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample,
+            "seconds": t_port}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accel", default="bvh", choices=["bvh", "brute"])
+    args = ap.parse_args()
+
+    import torch
+    import pyrt
+    from pyrt import dist as rdist
+
+    rank, world, local = rdist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d (launch with torch.distributed.run)" % (world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    kind, w, h, spp, mode, nph, k = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    scene = pyrt.Scene(kind, w, h)
+    ctx = pyrt.Context(scene, device=local)  # raises if the HIP library / a gfx950 device is missing
+    accel = pyrt.ACCEL_BRUTE if args.accel == "brute" else pyrt.ACCEL_BVH
+    use_ph = 1 if nph else 0
+    if nph:
+        pos, dr, wt = ctx.emit_photons(nph, seed=1)
+        kp, kd_, _ = pyrt.kd_order(pos, dr, wt)
+        ctx.set_photons(kp, kd_)
+    params = pyrt.make_params(w, h, spp, mode=mode, seed=1, accel=accel, rank=rank, world=world, tile=32,
+                              use_photons=use_ph, k=k, photons_requested=nph)
+
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    bg = torch.from_numpy(pyrt.background(w, h)).to(dev)
+    out = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        accum.zero_()
+        ctx.render_device(params, accum.data_ptr(), stream)
+        rdist.reduce_frame(accum, dst=0)
+        if rank == 0:
+            ctx.resolve_device(w, h, spp, accum.data_ptr(), bg.data_ptr(), out.data_ptr(), stream)
+
+    # one counted pass (untimed): rays, BVH node fetches and triangle tests are
+    # deterministic per frame, so they are measured once
+    params.collect_stats = 1
+    accum.zero_()
+    st = ctx.render_device(params, accum.data_ptr(), stream, stats=True)
+    params.collect_stats = 0
+    local_counts = [st.rays_closest, st.rays_shadow, st.nodes_visited, st.tris_tested, st.samples, st.knn_queries,
+                    st.kd_visited]
+    tot = rdist.sum_over_ranks(local_counts, dev)
+    rays_per_frame = tot[0] + tot[1]
+
+    for _ in range(args.warmup):
+        step()
+    rdist.barrier()
+    torch.cuda.synchronize()
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    rdist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = rdist.max_over_ranks(elapsed, dev)
+    kernel_ms, launches = ctx.profile_collect()
+
+    # roofline of the dominant kernel (k_render) on THIS rank: algorithmic bytes per
+    # launch (64 B per BVH node record fetched + 48 B per triangle record
+    # tested + 16 B per pixel-sample for the accumulator, + 32 B per kd node visited)
+    alg_bytes = 64 * local_counts[2] + 48 * local_counts[3] + 16 * local_counts[4] + 32 * local_counts[6]
+    avg_ms = kernel_ms / max(launches, 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+
+    if rank == 0:
+        res = {
+            "metric": "Mrays/s (primary+secondary) at 1024x1024/128spp path trace",
+            "value": rays_per_frame * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s scene (%d triangles), %dx%d, -m %d -N %d, pixel RNG seed 1, %s"
+                                   % (args.workload, kind, scene.desc.n_triangles, w, h, mode, spp, args.accel),
+                       "parallelism": "tiles32x%d" % world,
+                       "rays_per_frame": rays_per_frame, "samples_per_frame": tot[4],
+                       "knn_queries_per_frame": tot[5]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_render", "kernel_ms_avg": avg_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "nodes_per_ray": tot[2] / max(rays_per_frame, 1), "tris_per_ray": tot[3] / max(rays_per_frame, 1),
+                         "note": "scene is %.2f MB: cache-resident, achieved counts algorithmic not HBM bytes"
+                                 % ((64 * ctx.bvh_info().n_nodes + 48 * scene.desc.n_triangles) / 1e6)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(kind, mode, spp)
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    rdist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

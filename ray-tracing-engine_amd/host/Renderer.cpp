@@ -1,0 +1,50 @@
+// Renderer.cpp — see Renderer.h.  Header-style (include-guarded) because the
+// reference application #includes "Renderer.cpp" from Main.cpp (source/Main.cpp:21).
+#pragma once
+#include "Renderer.h"
+
+#include <iostream>
+#include <vector>
+
+inline void Renderer::render(Image& image) {
+  const uint32_t w = static_cast<uint32_t>(image.width()), h = static_cast<uint32_t>(image.height());
+  GpuSession session(m_scene, GpuSettings::get().device);
+
+  rt_params p = {};
+  p.width = w, p.height = h;
+  p.spp = static_cast<uint32_t>(m_numRays);
+  p.mode = m_mode == PATHTRACE ? RT_MODE_PATH : RT_MODE_RAY;
+  p.max_depth = 3;  // calculateColorPath(ray, found, 0, 3) — Renderer.cpp:245,248
+  p.seed = GpuSettings::get().seed;
+  p.rng_mode = RT_RNG_PIXEL;
+  p.accel = GpuSettings::get().accel;
+  p.tile = 8;
+
+  // Renderer.cpp:209-213: the photon map and its kd-tree are built inside render();
+  // the map is a local there (the member stays empty, so a savePhotonMap() issued
+  // BEFORE render() writes an empty cloud, as in the reference).  We keep the member
+  // filled afterwards so that a later savePhotonMap() is useful.
+  if (m_numPhotons > 0) {
+    PhotonMap map(session.ctx(), m_numPhotons, m_scene.lightsources().size());
+    std::cout << "Constructing a kd-tree for the photon map." << std::endl;
+    kdtree tree(map.list().begin(), map.list().end());
+    if (!tree.empty()) {
+      std::vector<float> pos(3 * tree.size()), dir(3 * tree.size());
+      for (size_t i = 0; i < tree.size(); ++i)
+        for (int c = 0; c < 3; ++c)
+          pos[3 * i + c] = tree.nodes()[i].position()[c], dir[3 * i + c] = tree.nodes()[i].incomeDirection()[c];
+      GpuSession::check(rt_set_photons(session.ctx(), pos.data(), dir.data(), static_cast<uint32_t>(tree.size())),
+                        "rt_set_photons");
+      p.use_photons = 1, p.k = static_cast<uint32_t>(m_k), p.photons_requested = static_cast<uint32_t>(m_numPhotons);
+    }
+    m_photonMap = map;
+  }
+
+  Image result(w, h);
+  if (p.spp > 0) {
+    GpuSession::check(rt_render(session.ctx(), &p, image.data(), result.data(), nullptr, &m_stats), "rt_render");
+    std::cout << "Raytracing... [" << std::string(50, '#') << "] 100%" << std::endl;
+    result.savePPM("update.ppm");
+    image = result;
+  }
+}

@@ -1,0 +1,77 @@
+"""The host layer end to end on the GPU: our RayTracer application and the
+reference's OWN Main.cpp compiled unchanged against our host headers
+(oracle/_ref/RayTracer_dropin) must write the PPM the oracle predicts for pixel
+RNG seed 1, byte for byte."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+import pyrt
+
+pytestmark = pytest.mark.gpu
+
+APP = os.path.join(pyrt.ROOT, "ray-tracing-engine_amd", "bin", "RayTracer")
+DROPIN = os.path.join(pyrt.ROOT, "oracle", "_ref", "RayTracer_dropin")
+
+
+def _expected(kind, w, h, spp, mode, nph=0, k=0):
+    s = pyrt.Scene(kind, w, h)
+    bg = pyrt.background(w, h)
+    p = pyrt.make_params(w, h, spp, mode=mode, seed=1)
+    ext = None
+    if nph:
+        ph, _, _ = orc.emit_photons(s, nph, pyrt.RNG_PIXEL, seed=1, math_mode=orc.MATH_DET)
+        ext = orc.kd_build(ph)
+        p.use_photons, p.k, p.photons_requested = 1, k, nph
+    out, _, _ = orc.render(s, p, math_mode=orc.MATH_DET, bg=bg, ext_photons=ext)
+    return orc.ppm_bytes(out)
+
+
+@pytest.mark.parametrize("args,exp", [
+    (["-width", "64", "-height", "48", "-m", "1", "-N", "4"], ("cubes", 64, 48, 4, 1)),
+    (["-w", "40", "-h", "40", "-m", "0", "-n", "3", "-scene", "lowres"], ("lowres", 40, 40, 3, 0)),
+    (["-width", "48", "-height", "48", "-m", "0", "-N", "2", "-p", "3000", "-k", "10"], ("cubes", 48, 48, 2, 0, 3000, 10)),
+    (["-width", "32", "-height", "32", "-m", "1", "-N", "2", "-p", "2000", "-k", "5", "-accel", "1"], ("cubes", 32, 32, 2, 1, 2000, 5)),
+])
+def test_application_writes_the_predicted_ppm(tmp_path, args, exp):
+    out = tmp_path / "o.ppm"
+    r = subprocess.run([APP] + args + ["-meshdir", pyrt.MESH_DIR, "-o", str(out)], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert out.read_bytes() == _expected(*exp)
+    assert (tmp_path / "update.ppm").read_bytes() == out.read_bytes()  # Renderer.cpp:268-269
+    assert "Mrays/s" in r.stdout
+    if "-p" in args:
+        # Main.cpp:216 + SURVEY App. A.9: the cloud saved BEFORE render() is empty
+        assert "POINTS 0" in (tmp_path / "pointcloud.pcd").read_text()
+
+
+def test_application_usage_errors(tmp_path):
+    r = subprocess.run([APP, "-width"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "Missing argument" in r.stderr and "USAGE" in r.stderr
+    r = subprocess.run([APP, "-bogus", "1"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "Unknown argument <-bogus>" in r.stderr
+    r = subprocess.run([APP, "-scene", "lowres", "-meshdir", str(tmp_path), "-N", "1"], capture_output=True, text=True,
+                       cwd=tmp_path)
+    assert r.returncode == 1 and "Error loading OFF file" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/RayTracer_dropin is built only where /root/reference exists")
+def test_reference_main_unchanged_runs_on_the_gpu(tmp_path):
+    """reference source/Main.cpp (compiled as is) + our Renderer::render: config 1 of
+    BASELINE.json, hard-coded ../meshes paths and all."""
+    (tmp_path / "build").mkdir()
+    os.symlink(pyrt.MESH_DIR, tmp_path / "meshes")
+    r = subprocess.run([DROPIN, "-width", "256", "-height", "256", "-m", "1", "-N", "8"], cwd=tmp_path / "build",
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = (tmp_path / "build" / "output.ppm").read_bytes()
+    assert got == _expected("cubes", 256, 256, 8, 1)
+    # and it is the same picture as the reference's up to Monte Carlo noise
+    ref = np.array(open(os.path.join(pyrt.ROOT, "tests", "golden", "ppm", "cubes_64_m1_N4.ppm")).read().split()[4:], float)
+    mine = np.array(got.split()[4:], float).reshape(256, 256, 3)
+    mine64 = mine.reshape(64, 4, 64, 4, 3).mean((1, 3))
+    assert abs(mine64.mean() - ref.mean()) / ref.mean() < 0.03
