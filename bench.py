@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accel", default="bvh", choices=["bvh", "brute"])
+    ap.add_argument("--leaf", type=int, default=0, help="BVH leaf size override (debug)")
     args = ap.parse_args()
 
     import torch
@@ -90,7 +91,7 @@ def main():
     if args.spp:
         spp = args.spp
     scene = pyrt.Scene(kind, w, h)
-    ctx = pyrt.Context(scene, device=local)  # raises if the HIP library / a gfx950 device is missing
+    ctx = pyrt.Context(scene, device=local, bvh_leaf_max=args.leaf)  # raises if the HIP library / a gfx950 device is missing
     accel = pyrt.ACCEL_BRUTE if args.accel == "brute" else pyrt.ACCEL_BVH
     use_ph = 1 if nph else 0
     if nph:

@@ -83,7 +83,7 @@ enum { RT_TRACE_CLOSEST = 0, RT_TRACE_ANY = 1 };
 
 typedef struct rt_options {
   int32_t device;          /* HIP device ordinal                              */
-  uint32_t bvh_leaf_max;   /* 0 = default (4)                                 */
+  uint32_t bvh_leaf_max;   /* 0 = default (2), max 8                          */
   uint32_t reserved[6];
 } rt_options;
 

@@ -49,7 +49,7 @@ struct Built {
   std::vector<Node> nodes;      // nodes[0] is the root
   std::vector<TriRec> tris;     // leaf order
   std::vector<TriRec> trisRef;  // reference order (brute-force kernel)
-  uint32_t maxDepth = 0, leafMax = 4;
+  uint32_t maxDepth = 0, leafMax = 2;
   float pad = 0.f;
 };
 

@@ -15,6 +15,8 @@
 // Built with -ffp-contract=off (bit parity with the x86-64 oracle, no FMA).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "bvh_build.h"
 #include "rt_device.h"
 #include "rt_kernels.h"
@@ -50,11 +52,15 @@ RT_DEV float safe_inv(float d) {
 RT_DEV f3 f4xyz(const float4& a) { return mk(a.x, a.y, a.z); }
 
 // Conservative slab test of one padded child box.  Returns entry distance in tn.
-RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 inv, float tmax,
+// t = lo*inv - o*inv as ONE fma per plane (this is our own box arithmetic, not a
+// reference expression, so contraction is allowed here): its absolute error is
+// ~ulp(o*inv) = 6e-8*|o|*|inv|, three orders below the box padding expressed in t
+// units (pad*|inv|, pad >= 6e-5*|o|max), so no padded box is ever wrongly culled.
+RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 inv, f3 oi, float tmax,
                  float& tn) {
-  float ax = (lx - o.x) * inv.x, bx = (hx - o.x) * inv.x;
-  float ay = (ly - o.y) * inv.y, by = (hy - o.y) * inv.y;
-  float az = (lz - o.z) * inv.z, bz = (hz - o.z) * inv.z;
+  float ax = __builtin_fmaf(lx, inv.x, -oi.x), bx = __builtin_fmaf(hx, inv.x, -oi.x);
+  float ay = __builtin_fmaf(ly, inv.y, -oi.y), by = __builtin_fmaf(hy, inv.y, -oi.y);
+  float az = __builtin_fmaf(lz, inv.z, -oi.z), bz = __builtin_fmaf(hz, inv.z, -oi.z);
   float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
   float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
   tn = tnear;
@@ -69,6 +75,7 @@ RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
 template <bool ANY, bool STATS>
 RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
   const f3 inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  const f3 oi = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
   float best = 3.402823466e+38f;  // numeric_limits<float>::max(), RayTracer.h:30
   uint32_t bestId = 0;
   bool found = false;
@@ -81,8 +88,8 @@ RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit
       const int4 ch = *reinterpret_cast<const int4*>(n + 3);
       if (STATS) st.nodes++;
       float t0, t1;
-      const bool h0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, best, t0);
-      const bool h1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, best, t1);
+      const bool h0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, inv, oi, best, t0);
+      const bool h1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, inv, oi, best, t1);
       if (h0 && h1) {
         const bool swap = t1 < t0;
         stack[sp * BLOCK] = (uint32_t)(swap ? ch.x : ch.y);
@@ -364,8 +371,8 @@ RT_DEV Lds carve_lds(uint32_t* base) {
 // ---------------------------------------------------------------- integrate
 // Renderer::render's per-sample body (Renderer.cpp:227-258) + calculateColorRay /
 // calculateColorPath (:106-201) with the recursion unrolled to a loop.
-template <bool BRUTE, bool PHOTON, bool STATS>
-__global__ __launch_bounds__(BLOCK) void k_render(DevScene S, RenderArgs A, float4* __restrict__ accum,
+template <bool BRUTE, bool PHOTON, bool STATS, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A, float4* __restrict__ accum,
                                                   unsigned long long* __restrict__ counters) {
   __shared__ uint32_t lds[(STACK + (PHOTON ? 2 * KMAX : 0)) * BLOCK];
   const Lds L = carve_lds<PHOTON>(lds);
@@ -617,8 +624,11 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
                                  unsigned long long* counters, hipStream_t stream) {
   const uint32_t blocks = (A.n_tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
   if (blocks == 0) return hipSuccess;
-  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true>), dim3(blocks), dim3(BLOCK), 0, stream, S, A, accum, counters);
-  else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false>), dim3(blocks), dim3(BLOCK), 0, stream, S, A, accum, counters);
+  // MINW = 4 waves/SIMD (<= 128 VGPRs): measured +16 % over the unconstrained
+  // 134-VGPR / 3-wave build on C2; the photon variant is LDS-limited to 2 anyway
+  constexpr int MINW = PHOTON ? 1 : 4;
+  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true, 1>), dim3(blocks), dim3(BLOCK), 0, stream, S, A, accum, counters);
+  else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false, MINW>), dim3(blocks), dim3(BLOCK), 0, stream, S, A, accum, counters);
   return hipGetLastError();
 }
 
