@@ -25,7 +25,7 @@ using namespace rtd;
 
 namespace rtk {
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK = 64;
 constexpr int STACK = rtbvh::kMaxDepth;  // 32 words per lane
 constexpr int KMAX = RTK_KMAX;           // photon heap capacity per lane
 
@@ -80,9 +80,15 @@ RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit
   uint32_t bestId = 0;
   bool found = false;
   int sp = 0;
+  constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane's ray is finished"
   int32_t cur = 0;
+  // "while-while": the wave first descends inner nodes until EVERY live lane holds
+  // a leaf (lanes that already have one sit out, masked), then all leaves are
+  // intersected together.  Each wave iteration therefore runs one kind of work
+  // instead of the union of both (measured lane utilisation of the single-loop
+  // form on incoherent rays: 34 %).
   for (;;) {
-    if (cur >= 0) {
+    while (cur >= 0) {
       const float4* n = S.nodes + 4 * (size_t)cur;
       const float4 a = n[0], b = n[1], c = n[2];
       const int4 ch = *reinterpret_cast<const int4*>(n + 3);
@@ -95,19 +101,19 @@ RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit
         stack[sp * BLOCK] = (uint32_t)(swap ? ch.x : ch.y);
         sp++;
         cur = swap ? ch.y : ch.x;
-        continue;
+      } else if (h0 || h1) {
+        cur = h0 ? ch.x : ch.y;
+      } else if (sp > 0) {
+        sp--;
+        cur = (int32_t)stack[sp * BLOCK];
+      } else {
+        cur = TERM;
       }
-      if (h0) {
-        cur = ch.x;
-        continue;
-      }
-      if (h1) {
-        cur = ch.y;
-        continue;
-      }
-    } else {
+    }
+    if (cur != TERM) {
       const uint32_t code = ~(uint32_t)cur;
       const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+      bool stop = false;
       for (uint32_t i = 0; i < cnt; i++) {
         const float4* r = S.tris + 3 * (size_t)(first + i);
         const float4 q0 = r[0], q1 = r[1], q2 = r[2];
@@ -115,7 +121,10 @@ RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit
         float u, v, t;
         if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t) &&
             t > 0.f) {
-          if (ANY) return true;
+          if (ANY) {
+            found = true, stop = true;
+            break;
+          }
           const uint32_t id = __float_as_uint(q2.y);
           if (t < best || (t == best && id < bestId)) {
             best = t, bestId = id, found = true;
@@ -123,10 +132,14 @@ RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit
           }
         }
       }
+      if (stop || sp == 0) {
+        cur = TERM;
+      } else {
+        sp--;
+        cur = (int32_t)stack[sp * BLOCK];
+      }
     }
-    if (sp == 0) break;
-    sp--;
-    cur = (int32_t)stack[sp * BLOCK];
+    if (__ballot(cur != TERM) == 0) break;
   }
   return found;
 }
