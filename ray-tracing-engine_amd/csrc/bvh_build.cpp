@@ -153,6 +153,41 @@ struct Builder {
   }
 };
 
+// float -> binary16 with directed rounding (toward -inf when up == false, toward
+// +inf when up == true).  Inputs are finite and |x| <= 32768 by construction.
+uint16_t toHalfDirected(float x, bool up) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  const uint32_t sign = u >> 31;
+  const float ax = std::fabs(x);
+  // away-from-zero rounding of the magnitude is needed iff the direction matches the sign
+  const bool away = (up && !sign) || (!up && sign);
+  uint32_t h;
+  if (ax == 0.f) {
+    h = 0;
+  } else if (ax < 6.103515625e-05f) {  // below the smallest normal half: fixed-point with 2^-24 steps
+    const float q = ax * 16777216.f;   // exact
+    uint32_t m = static_cast<uint32_t>(q);
+    if (away && static_cast<float>(m) < q) ++m;
+    h = m;                             // m == 1024 carries into the smallest normal, as it should
+  } else {
+    uint32_t au = u & 0x7fffffffu;
+    const uint32_t lost = au & 0x1fffu;  // 13 mantissa bits do not fit
+    au >>= 13;
+    if (away && lost) ++au;              // a carry walks into the exponent, as it should
+    h = au - ((127u - 15u) << 10);
+  }
+  return static_cast<uint16_t>((sign << 15) | h);
+}
+
+float halfToFloat(uint16_t hv) {
+  const uint32_t sign = (hv >> 15) & 1u, e = (hv >> 10) & 31u, m = hv & 1023u;
+  float v;
+  if (e == 0) v = static_cast<float>(m) * 5.9604644775390625e-08f;  // 2^-24
+  else v = std::ldexp(static_cast<float>(m | 1024u), static_cast<int>(e) - 25);
+  return sign ? -v : v;
+}
+
 TriRec makeRec(const rt_scene_desc& sc, uint32_t t, uint32_t mesh) {
   TriRec r;
   const float* p0 = sc.vertex_pos + 3 * static_cast<size_t>(sc.tri_vtx[3 * static_cast<size_t>(t) + 0]);
@@ -228,6 +263,24 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out) {
   }
   out.tris.resize(sc.n_triangles);
   for (uint32_t i = 0; i < sc.n_triangles; ++i) out.tris[i] = out.trisRef[B.prims[i].id];
+
+  // packed device nodes
+  int e = 0;
+  std::frexp(32768.f / std::max(maxAbs + out.pad, 1e-30f), &e);  // value = m * 2^e, m in [0.5,1)
+  out.boxScale = std::ldexp(1.f, std::min(std::max(e - 1, -100), 100));
+  out.nodes16.resize(out.nodes.size());
+  for (size_t i = 0; i < out.nodes.size(); ++i) {
+    const Node& n = out.nodes[i];
+    Node16& q = out.nodes16[i];
+    for (int a = 0; a < 3; ++a) {
+      q.lo0[a] = toHalfDirected(n.lo0[a] * out.boxScale, false), q.hi0[a] = toHalfDirected(n.hi0[a] * out.boxScale, true);
+      q.lo1[a] = toHalfDirected(n.lo1[a] * out.boxScale, false), q.hi1[a] = toHalfDirected(n.hi1[a] * out.boxScale, true);
+      if (halfToFloat(q.lo0[a]) > n.lo0[a] * out.boxScale || halfToFloat(q.hi0[a]) < n.hi0[a] * out.boxScale ||
+          halfToFloat(q.lo1[a]) > n.lo1[a] * out.boxScale || halfToFloat(q.hi1[a]) < n.hi1[a] * out.boxScale)
+        throw std::runtime_error("internal error: packed box does not contain the float box");
+    }
+    q.child[0] = n.child[0], q.child[1] = n.child[1];
+  }
 }
 
 }  // namespace rtbvh

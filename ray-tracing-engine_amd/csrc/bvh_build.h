@@ -25,13 +25,25 @@
 
 namespace rtbvh {
 
-struct alignas(16) Node {   // 64 B
+struct alignas(16) Node {   // 64 B, full-precision form (host build, tests)
   float lo0[3], hi0[3];     // box of child 0
   float lo1[3], hi1[3];     // box of child 1
   int32_t child[2];         // >= 0: node index; < 0: leaf, ~child = first << 3 | (count - 1)
   uint32_t pad[2];
 };
 static_assert(sizeof(Node) == 64, "node record must be 64 bytes");
+
+// What the GPU traverses: the same node with its 12 box planes stored as IEEE
+// binary16 of (coordinate * boxScale), lower planes rounded DOWN and upper planes
+// rounded UP, so a packed box always contains the float box.  Halves the bytes a
+// lane pulls through the CU's 64 B/clk L1 data path per traversal step — the unit
+// that bounds this kernel on cache-resident scenes.  boxScale is a power of two
+// (exact) chosen so that |coordinate * boxScale| <= 32768.
+struct alignas(16) Node16 {  // 32 B
+  uint16_t lo0[3], hi0[3], lo1[3], hi1[3];
+  int32_t child[2];
+};
+static_assert(sizeof(Node16) == 32, "packed node record must be 32 bytes");
 
 struct alignas(16) TriRec { // 48 B
   float p0[3], e1[3], e2[3];
@@ -47,6 +59,8 @@ inline int32_t encodeLeaf(uint32_t first, uint32_t count) { return ~static_cast<
 
 struct Built {
   std::vector<Node> nodes;      // nodes[0] is the root
+  std::vector<Node16> nodes16;  // device form of `nodes`
+  float boxScale = 1.f;         // power of two applied before the f16 conversion
   std::vector<TriRec> tris;     // leaf order
   std::vector<TriRec> trisRef;  // reference order (brute-force kernel)
   uint32_t maxDepth = 0, leafMax = 2;

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -171,6 +172,8 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   A.s1 = p->spp_count ? p->spp_begin + p->spp_count : p->spp;
   A.mode = p->mode, A.max_depth = p->max_depth, A.seed = p->seed;
   A.k = p->k, A.photons_requested = p->photons_requested;
+  static const bool noPool = getenv("RT_NO_POOL") != nullptr;
+  A.flags = noPool ? 0u : 1u;
   const int e = c->evUsed % kEventPairs;
   HIP_TRY(hipEventRecord(c->ev[e][0], stream));
   hipError_t he = rtk::launch_render(p->accel == RT_ACCEL_BRUTE, p->use_photons != 0, p->collect_stats != 0, c->S, A,
@@ -208,7 +211,7 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
     delete c;
     return fail(RT_ERR_INVALID, "scene rejected: %s", e.what());
   }
-  static_assert(sizeof(rtbvh::Node) == 4 * sizeof(float4), "node layout");
+  static_assert(sizeof(rtbvh::Node16) == 2 * sizeof(uint4), "node layout");
   static_assert(sizeof(rtbvh::TriRec) == 3 * sizeof(float4), "triangle layout");
   std::vector<uint4> shade(sc->n_triangles);
   for (uint32_t m = 0; m < sc->n_meshes; ++m)
@@ -221,7 +224,7 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
     rt_destroy(c);                                         \
     return rc;                                             \
   }
-  UP(nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4);
+  UP(nodes, c->bvh.nodes16.data(), c->bvh.nodes16.size() * 2);
   UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);
   UP(trisRef, c->bvh.trisRef.data(), c->bvh.trisRef.size() * 3);
   UP(triShade, shade.data(), shade.size());
@@ -236,6 +239,7 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
   S.n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
   S.n_lights = sc->n_lights;
   S.n_photons = 0;
+  S.invBoxScale = 1.f / c->bvh.boxScale;
   S.phPos = S.phDir = nullptr;
   S.cam = sc->camera;
   if (hipMalloc(reinterpret_cast<void**>(&c->dCounters), RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||

@@ -23,7 +23,7 @@ namespace rtk {
 
 // Device-resident flattened scene (all pointers are HBM allocations of rt_ctx).
 struct DevScene {
-  const float4* nodes;     // n_nodes x 64 B: {lo0.xyz,hi0.x}{hi0.yz,lo1.xy}{lo1.z,hi1.xyz}{c0,c1,-,-}
+  const uint4* nodes;      // n_nodes x 32 B: 12 x f16 box planes (lo0 hi0 lo1 hi1, scaled) + 2 child refs
   const float4* tris;      // n_tris x 48 B, BVH leaf order: {p0,e1.x}{e1.yz,e2.xy}{e2.z,id,mesh,-}
   const float4* trisRef;   // same records in reference (mesh,tri) order (brute-force path)
   const uint4* triShade;   // per global triangle id: {v0,v1,v2 (global vertex ids), mesh}
@@ -36,6 +36,7 @@ struct DevScene {
   const float4* phPos;     // photons in kd-tree order: xyz + pad
   const float4* phDir;     // income direction xyz + weight
   uint32_t n_tris, n_nodes, n_lights, n_photons;
+  float invBoxScale;       // 1 / rtbvh::Built::boxScale
   rt_camera cam;
 };
 
@@ -43,6 +44,7 @@ struct RenderArgs {
   const uint32_t* tiles;  // owned 8x8 tiles, x8 | y8 << 16
   uint32_t n_tiles;
   uint32_t width, height, spp, s0, s1, mode, max_depth, seed, k, photons_requested;
+  uint32_t flags;         // bit 0: shadow rays through the wave-level pool
 };
 
 hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,

@@ -56,6 +56,9 @@ RT_DEV f3 f4xyz(const float4& a) { return mk(a.x, a.y, a.z); }
 // reference expression, so contraction is allowed here): its absolute error is
 // ~ulp(o*inv) = 6e-8*|o|*|inv|, three orders below the box padding expressed in t
 // units (pad*|inv|, pad >= 6e-5*|o|max), so no padded box is ever wrongly culled.
+RT_DEV float h2f_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+RT_DEV float h2f_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+
 RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 inv, f3 oi, float tmax,
                  float& tn) {
   float ax = __builtin_fmaf(lx, inv.x, -oi.x), bx = __builtin_fmaf(hx, inv.x, -oi.x);
@@ -67,35 +70,47 @@ RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
   return tnear <= fminf(tfar * 1.0000005f, tmax);
 }
 
-// RayTracer::rayTrace (RayTracer.h:27-53) through the flattened BVH.
-//   ANY = false: closest positive t; on equal t the lowest global triangle id wins
-//                (== the reference's strict '<' in mesh-then-triangle order)
-//   ANY = true : returns at the first accepted triangle with t > 0 (Renderer.cpp:54
-//                only uses the bool)
-template <bool ANY, bool STATS>
-RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
-  const f3 inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-  const f3 oi = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-  float best = 3.402823466e+38f;  // numeric_limits<float>::max(), RayTracer.h:30
-  uint32_t bestId = 0;
-  bool found = false;
-  int sp = 0;
-  constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane's ray is finished"
-  int32_t cur = 0;
-  // "while-while": the wave first descends inner nodes until EVERY live lane holds
-  // a leaf (lanes that already have one sit out, masked), then all leaves are
-  // intersected together.  Each wave iteration therefore runs one kind of work
-  // instead of the union of both (measured lane utilisation of the single-loop
-  // form on incoherent rays: 34 %).
-  for (;;) {
+constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane holds no live ray"
+
+// One lane's ray in flight.  round() advances every lane of the wave that holds a
+// live ray by one "while-while" round: first the wave descends inner nodes until
+// EVERY live lane holds a leaf (lanes that already have one sit out, masked), then
+// all leaves are intersected together — each wave iteration runs one kind of work
+// instead of the union of both (the single-loop form measured 34 % lane utilisation
+// on incoherent rays).  Between rounds a caller may hand finished lanes new rays
+// (shadow-ray pool below).
+template <bool ANY>
+struct Trav {
+  f3 o, d, inv, oi;
+  float best;
+  uint32_t bestId;
+  bool found;
+  int sp;
+  int32_t cur;
+  HitRec hit;
+
+  RT_DEV void idle() { cur = TERM, found = false, sp = 0; }
+  RT_DEV void start(f3 o_, f3 d_, float invScale) {
+    o = o_, d = d_;
+    const f3 i1 = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    oi = mk(o.x * i1.x, o.y * i1.y, o.z * i1.z);
+    // boxes are stored as coordinate * boxScale (a power of two): fold 1/boxScale in
+    inv = mk(i1.x * invScale, i1.y * invScale, i1.z * invScale);
+    best = 3.402823466e+38f;  // numeric_limits<float>::max(), RayTracer.h:30
+    bestId = 0, found = false, sp = 0, cur = 0;
+  }
+  RT_DEV bool live() const { return cur != TERM; }
+
+  template <bool STATS>
+  RT_DEV void round(const DevScene& S, uint32_t* stack, LaneStats& st) {
     while (cur >= 0) {
-      const float4* n = S.nodes + 4 * (size_t)cur;
-      const float4 a = n[0], b = n[1], c = n[2];
-      const int4 ch = *reinterpret_cast<const int4*>(n + 3);
+      const uint4* n = S.nodes + 2 * (size_t)cur;  // 32-B packed node: 12 x f16 planes + 2 refs
+      const uint4 a = n[0], b = n[1];
+      const int2 ch = make_int2((int)b.z, (int)b.w);
       if (STATS) st.nodes++;
       float t0, t1;
-      const bool h0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, inv, oi, best, t0);
-      const bool h1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, inv, oi, best, t1);
+      const bool h0 = slab(h2f_lo(a.x), h2f_hi(a.x), h2f_lo(a.y), h2f_hi(a.y), h2f_lo(a.z), h2f_hi(a.z), inv, oi, best, t0);
+      const bool h1 = slab(h2f_lo(a.w), h2f_hi(a.w), h2f_lo(b.x), h2f_hi(b.x), h2f_lo(b.y), h2f_hi(b.y), inv, oi, best, t1);
       if (h0 && h1) {
         const bool swap = t1 < t0;
         stack[sp * BLOCK] = (uint32_t)(swap ? ch.x : ch.y);
@@ -139,9 +154,23 @@ RT_DEV bool traverse(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit
         cur = (int32_t)stack[sp * BLOCK];
       }
     }
-    if (__ballot(cur != TERM) == 0) break;
   }
-  return found;
+};
+
+// RayTracer::rayTrace (RayTracer.h:27-53) through the flattened BVH.
+//   ANY = false: closest positive t; on equal t the lowest global triangle id wins
+//                (== the reference's strict '<' in mesh-then-triangle order)
+//   ANY = true : stops at the first accepted triangle with t > 0 (Renderer.cpp:54
+//                only uses the bool)
+// `on` = this lane has a ray; lanes without one still take part in the wave loop.
+template <bool ANY, bool STATS>
+RT_DEV bool traverse(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
+  Trav<ANY> T;
+  T.idle();
+  if (on) T.start(o, d, S.invBoxScale);
+  while (__ballot(T.live()) != 0) T.template round<STATS>(S, stack, st);
+  if (!ANY && T.found) hit = T.hit;
+  return T.found;
 }
 
 // The reference algorithm itself: every triangle, reference order (RayTracer.h:32-51).
@@ -165,10 +194,11 @@ RT_DEV bool brute(const DevScene& S, f3 o, f3 d, HitRec& hit, LaneStats& st) {
   return found;
 }
 
+// `on`: lanes without a ray pass false (wave-uniform call sites, no early exits).
 template <bool BRUTE, bool ANY, bool STATS>
-RT_DEV bool cast(const DevScene& S, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
-  if (BRUTE) return brute<ANY, STATS>(S, o, d, hit, st);
-  return traverse<ANY, STATS>(S, o, d, stack, hit, st);
+RT_DEV bool cast(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
+  if (BRUTE) return on && brute<ANY, STATS>(S, o, d, hit, st);
+  return traverse<ANY, STATS>(S, on, o, d, stack, hit, st);
 }
 
 // Renderer.cpp:274-277 dotArr: (w*a + u*b) + v*c per component
@@ -307,44 +337,131 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
 }
 
 // ---------------------------------------------------------------- shading
-// Renderer.cpp:33-61 (direct lighting with shadow rays) / :63-104 (photon map).
-template <bool BRUTE, bool PHOTON, bool STATS>
-RT_DEV f3 shade(const DevScene& S, const RenderArgs& A, Rng& g, f3 rayDir, const HitRec& h, const Lds& L,
-                f3& hitNormal, f3& point, LaneStats& st) {
+constexpr int POOL_L = 4;                              // lights handled by the shadow-ray pool
+constexpr int POOL_WORDS = 192 + POOL_L * 192 + 64 + 2 * POOL_L;  // per wave, 32-bit words
+
+RT_DEV uint32_t lanes_below(uint64_t m) {  // number of set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Renderer.cpp:42-43: interpolated shading normal and hit point
+RT_DEV void vertex_setup(const DevScene& S, const HitRec& h, f3& hitNormal, f3& point) {
   const float w = 1.f - h.u - h.v;
   const uint4 tv = S.triShade[h.id];
   hitNormal = unit3(interp3(S.vnrm, tv, w, h.u, h.v));
   point = interp3(S.vpos, tv, w, h.u, h.v);
+}
+
+// Renderer.cpp:63-104: photon-map radiance estimate at the vertex
+template <bool STATS>
+RT_DEV f3 shade_photon(const DevScene& S, const RenderArgs& A, f3 rayDir, const HitRec& h, const Lds& L, f3 hitNormal,
+                       f3 point, LaneStats& st) {
+  const rt_material mat = S.mats[h.mesh];
+  const Heap H{L.heapD, L.heapI};
+  const int k = (int)A.k;
+  st.knn++;
+  const uint32_t vis = knn_query(S, point, k, H, reinterpret_cast<float*>(L.stack));
+  if (STATS) st.kd += vis;
+  const float4 far = S.phPos[H.I(k - 1)];
+  const float r = dist3(mk(far.x, far.y, far.z), point);
+  const float area = (float)(3.14159265358979323846 * (double)r * (double)r);
+  f3 avg = mk(0.f, 0.f, 0.f), radiance = mk(0.f, 0.f, 0.f);
+  for (int j = 0; j < k; j++) {
+    avg = avg + f4xyz(S.phDir[H.I(j)]);
+    radiance = radiance + mk(1.f, 1.f, 1.f);
+  }
+  radiance = radiance / area;
+  radiance = radiance / (float)(int)A.photons_requested;
+  radiance = radiance * 100.f;  // Renderer.h:45
+  const f3 bsdf = bsdf_eval(mat, hitNormal, unit3(avg), -rayDir);
+  return mk(0.f, 0.f, 0.f) + radiance * bsdf;
+}
+
+// Renderer.cpp:49-60, one light after the other (brute-force variant and scenes
+// with more than POOL_L lights).  Called by lanes that own a vertex only.
+template <bool BRUTE, bool STATS>
+RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h, uint32_t* stack, f3 hitNormal,
+                           f3 point, LaneStats& st) {
   const rt_material mat = S.mats[h.mesh];
   f3 color = mk(0.f, 0.f, 0.f);
-  if (PHOTON) {
-    const Heap H{L.heapD, L.heapI};
-    const int k = (int)A.k;
-    st.knn++;
-    const uint32_t vis = knn_query(S, point, k, H, reinterpret_cast<float*>(L.stack));
-    if (STATS) st.kd += vis;
-    const float4 far = S.phPos[H.I(k - 1)];
-    const float r = dist3(mk(far.x, far.y, far.z), point);
-    const float area = (float)(3.14159265358979323846 * (double)r * (double)r);
-    f3 avg = mk(0.f, 0.f, 0.f), radiance = mk(0.f, 0.f, 0.f);
-    for (int j = 0; j < k; j++) {
-      avg = avg + f4xyz(S.phDir[H.I(j)]);
-      radiance = radiance + mk(1.f, 1.f, 1.f);
-    }
-    radiance = radiance / area;
-    radiance = radiance / (float)(int)A.photons_requested;
-    radiance = radiance * 100.f;  // Renderer.h:45
-    const f3 bsdf = bsdf_eval(mat, hitNormal, unit3(avg), -rayDir);
+  for (uint32_t li = 0; li < S.n_lights; li++) {
+    const rt_light Lt = S.lights[li];
+    const f3 toLight = light_sample(g, Lt) - point;
+    HitRec tmp;
+    st.shadow++;
+    if (cast<BRUTE, true, STATS>(S, true, point, toLight, stack, tmp, st)) continue;
+    const f3 bsdf = bsdf_eval(mat, hitNormal, toLight, -rayDir);
+    const f3 radiance = light_eval(Lt, point);
     color = color + radiance * bsdf;
-  } else {
-    for (uint32_t li = 0; li < S.n_lights; li++) {
-      const rt_light Lt = S.lights[li];
-      const f3 toLight = light_sample(g, Lt) - point;
-      HitRec tmp;
-      st.shadow++;
-      if (cast<BRUTE, true, STATS>(S, point, toLight, L.stack, tmp, st)) continue;
+  }
+  return color;
+}
+
+// Renderer.cpp:49-60 for a whole wave at once.  The light samples of a vertex do
+// not depend on the shadow tests (the reference draws them unconditionally, in
+// light order), so all n_lights x (lanes with a vertex) shadow rays are known up
+// front.  They go into an LDS pool and the 64 lanes work through it as WORKERS:
+// a lane whose ray is decided fetches the next undecided one (__ballot + mbcnt
+// compaction, no atomics), instead of idling until the slowest of 64 rays ends —
+// any-hit rays end at very different times (occluded ones early).  Results come
+// back as one bit per (light, lane); the BSDF is then evaluated per pixel lane in
+// light order, i.e. the float sum is formed exactly as the sequential loop forms it.
+// Must be called in wave-uniform control flow (workgroup == one wave).
+template <bool STATS>
+RT_DEV f3 shade_direct_pool(const DevScene& S, Rng& g, bool alive, f3 rayDir, const HitRec& h, uint32_t* stack,
+                            uint32_t* pool, f3 hitNormal, f3 point, LaneStats& st) {
+  const uint32_t lane = threadIdx.x, nl = S.n_lights;
+  float* vo = reinterpret_cast<float*>(pool);
+  float* vd = vo + 192;
+  uint32_t* list = pool + 192 + POOL_L * 192;
+  uint32_t* res = list + 64;
+  const uint64_t amask = __ballot(alive);
+  const uint32_t n = (uint32_t)__popcll(amask);
+  f3 color = mk(0.f, 0.f, 0.f);
+  if (n == 0) return color;
+  if (alive) {
+    vo[lane] = point.x, vo[64 + lane] = point.y, vo[128 + lane] = point.z;
+    for (uint32_t l = 0; l < nl; l++) {
+      const f3 tl = light_sample(g, S.lights[l]) - point;
+      vd[(l * 3 + 0) * 64 + lane] = tl.x, vd[(l * 3 + 1) * 64 + lane] = tl.y, vd[(l * 3 + 2) * 64 + lane] = tl.z;
+    }
+    list[lanes_below(amask)] = lane;
+    st.shadow += nl;
+  }
+  if (lane < 2 * POOL_L) res[lane] = 0;
+  __syncthreads();
+  const uint32_t R = n * nl;
+  uint32_t head = 0, myL = 0, myJ = 0;
+  Trav<true> T;
+  T.idle();
+  for (;;) {
+    const uint64_t idle = __ballot(!T.live());
+    if (head < R && idle != 0) {
+      if (!T.live()) {
+        const uint32_t r = head + lanes_below(idle);
+        if (r < R) {
+          const uint32_t l = (r >= n) + (r >= 2 * n) + (r >= 3 * n);
+          const uint32_t j = list[r - l * n];
+          T.start(mk(vo[j], vo[64 + j], vo[128 + j]),
+                  mk(vd[(l * 3 + 0) * 64 + j], vd[(l * 3 + 1) * 64 + j], vd[(l * 3 + 2) * 64 + j]), S.invBoxScale);
+          myL = l, myJ = j;
+        }
+      }
+      head += (uint32_t)__popcll(idle);
+    }
+    if (__ballot(T.live()) == 0) break;
+    const bool was = T.live();
+    T.template round<STATS>(S, stack, st);
+    if (was && !T.live() && T.found) atomicOr(&res[myL * 2 + (myJ >> 5)], 1u << (myJ & 31));
+  }
+  __syncthreads();
+  if (alive) {
+    const rt_material mat = S.mats[h.mesh];
+    for (uint32_t l = 0; l < nl; l++) {
+      if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
+      const f3 toLight = mk(vd[(l * 3 + 0) * 64 + lane], vd[(l * 3 + 1) * 64 + lane], vd[(l * 3 + 2) * 64 + lane]);
       const f3 bsdf = bsdf_eval(mat, hitNormal, toLight, -rayDir);
-      const f3 radiance = light_eval(Lt, point);
+      const f3 radiance = light_eval(S.lights[l], point);
       color = color + radiance * bsdf;
     }
   }
@@ -383,56 +500,74 @@ RT_DEV Lds carve_lds(uint32_t* base) {
 
 // ---------------------------------------------------------------- integrate
 // Renderer::render's per-sample body (Renderer.cpp:227-258) + calculateColorRay /
-// calculateColorPath (:106-201) with the recursion unrolled to a loop.
+// calculateColorPath (:106-201) with the recursion unrolled to a loop.  Control
+// flow is wave-uniform (per-lane `alive` flags instead of early exits) because the
+// direct-lighting step exchanges rays between lanes through LDS.
 template <bool BRUTE, bool PHOTON, bool STATS, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A, float4* __restrict__ accum,
                                                   unsigned long long* __restrict__ counters) {
-  __shared__ uint32_t lds[(STACK + (PHOTON ? 2 * KMAX : 0)) * BLOCK];
+  static_assert(BLOCK == 64, "the shadow-ray pool assumes one wave per workgroup");
+  constexpr bool POOLED = !BRUTE && !PHOTON;
+  __shared__ uint32_t lds[(STACK + (PHOTON ? 2 * KMAX : 0)) * BLOCK + (POOLED ? POOL_WORDS : 0)];
   const Lds L = carve_lds<PHOTON>(lds);
-  const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-  const uint32_t lane = threadIdx.x & 63;
+  uint32_t* pool = lds + (STACK + (PHOTON ? 2 * KMAX : 0)) * BLOCK;
+  const uint32_t wave = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
   LaneStats st;
   if (wave < A.n_tiles) {
     const uint32_t tile = A.tiles[wave];
     const uint32_t px = (tile & 0xffffu) * 8u + (lane & 7u), py = (tile >> 16) * 8u + (lane >> 3);
-    if (px < A.width && py < A.height) {
-      const uint32_t pix = py * A.width + px;
-      float4 sum = accum[pix];
-      for (uint32_t i = A.s0; i < A.s1; i++) {
-        Rng g{rt_stream_seed(A.seed, RT_STREAM_PIXEL, pix, i)};
-        float sx, sy;
-        jitter_sample(g, (int)i, (int)A.spp, sx, sy);
-        f3 o, d;
-        camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
-        f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
-        bool primary = true;
-        const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
-        for (int depth = 0; depth < nvert; depth++) {
-          HitRec h;
-          st.closest++;
-          if (!cast<BRUTE, false, STATS>(S, o, d, L.stack, h, st)) {
-            if (depth == 0) primary = false;
-            break;
-          }
-          f3 nrm, pt;
-          const f3 c = shade<BRUTE, PHOTON, STATS>(S, A, g, d, h, L, nrm, pt, st);
+    const bool inImage = px < A.width && py < A.height;
+    const uint32_t pix = inImage ? py * A.width + px : 0u;
+    float4 sum = inImage ? accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool pooled = POOLED && (A.flags & 1u) && S.n_lights <= (uint32_t)POOL_L;
+    const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
+    for (uint32_t i = A.s0; i < A.s1; i++) {
+      Rng g{rt_stream_seed(A.seed, RT_STREAM_PIXEL, pix, i)};
+      float sx, sy;
+      jitter_sample(g, (int)i, (int)A.spp, sx, sy);
+      f3 o, d;
+      camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
+      f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
+      bool primary = true, alive = inImage;
+      for (int depth = 0; depth < nvert; depth++) {
+        HitRec h;
+        if (alive) st.closest++;
+        const bool hitv = cast<BRUTE, false, STATS>(S, alive, o, d, L.stack, h, st);
+        if (alive && !hitv) {
+          if (depth == 0) primary = false;
+          alive = false;
+        }
+        if (__ballot(alive) == 0) break;
+        f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, c = nrm;
+        if (alive) vertex_setup(S, h, nrm, pt);
+        if (PHOTON) {
+          if (alive) c = shade_photon<STATS>(S, A, d, h, L, nrm, pt, st);
+        } else if (pooled) {
+          c = shade_direct_pool<STATS>(S, g, alive, d, h, L.stack, pool, nrm, pt, st);
+        } else {
+          if (alive) c = shade_direct_seq<BRUTE, STATS>(S, g, d, h, L.stack, nrm, pt, st);
+        }
+        if (alive) {
           if (depth == 0) c0 = c;
           else if (depth == 1) c1 = c;
           else if (depth == 2) c2 = c;
           else c3 = c;
-          if (A.mode != RT_MODE_PATH) break;
+        }
+        if (A.mode != RT_MODE_PATH) break;
+        if (alive) {
           d = hemisphere_sample(g, nrm);  // drawn after every shaded vertex (Renderer.cpp:164)
           o = pt;
         }
-        // calculateColorPath returns c0 + (c1 + (c2 + (c3 + 0)))
-        const f3 total = c0 + (c1 + (c2 + (c3 + mk(0.f, 0.f, 0.f))));
-        sum.x += clamp01(total.x);
-        sum.y += clamp01(total.y);
-        sum.z += clamp01(total.z);
-        if (primary) sum.w += 1.f;
       }
-      accum[pix] = sum;
+      // calculateColorPath returns c0 + (c1 + (c2 + (c3 + 0)))
+      const f3 total = c0 + (c1 + (c2 + (c3 + mk(0.f, 0.f, 0.f))));
+      sum.x += clamp01(total.x);
+      sum.y += clamp01(total.y);
+      sum.z += clamp01(total.z);
+      if (primary) sum.w += 1.f;
     }
+    if (inImage) accum[pix] = sum;
   }
   flush_stats(st, counters, STATS);
 }
@@ -459,7 +594,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, const rt_ray* __res
   if (i < n) {
     HitRec h;
     const f3 o = ld(rays[i].origin), d = ld(rays[i].direction);
-    const bool found = cast<BRUTE, ANY, true>(S, o, d, lds + threadIdx.x, h, st);
+    const bool found = cast<BRUTE, ANY, true>(S, true, o, d, lds + threadIdx.x, h, st);
     rt_hit r;
     r.hit = found, r.mesh = 0, r.tri = 0, r.vtx[0] = r.vtx[1] = r.vtx[2] = 0, r.u = r.v = r.d = 0.f;
     if (found && !ANY) {
@@ -525,7 +660,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit(DevScene S, uint32_t perLight, u
       if (depth >= 20) break;
       HitRec h;
       st.closest++;
-      if (!cast<BRUTE, false, false>(S, o, d, stack, h, st)) {
+      if (!cast<BRUTE, false, false>(S, true, o, d, stack, h, st)) {
         stored = depth != 0;
         break;
       }
@@ -635,7 +770,7 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
 template <bool BRUTE, bool PHOTON>
 static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
                                  unsigned long long* counters, hipStream_t stream) {
-  const uint32_t blocks = (A.n_tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
+  const uint32_t blocks = A.n_tiles;
   if (blocks == 0) return hipSuccess;
   // MINW = 4 waves/SIMD (<= 128 VGPRs): measured +16 % over the unconstrained
   // 134-VGPR / 3-wave build on C2; the photon variant is LDS-limited to 2 anyway
