@@ -174,6 +174,15 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   A.k = p->k, A.photons_requested = p->photons_requested;
   static const bool noPool = getenv("RT_NO_POOL") != nullptr;
   A.flags = noPool ? 0u : 1u;
+  // stack entries: one per inner level on a root-to-leaf path; the photon k-NN
+  // keeps one split distance per kd level in the same region
+  uint32_t levels = c->bvh.maxDepth + 1;
+  if (p->use_photons) {
+    uint32_t kd = 1;
+    while ((1ull << kd) <= c->S.n_photons) ++kd;
+    levels = levels > kd + 1 ? levels : kd + 1;
+  }
+  A.stackLevels = levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels;
   const int e = c->evUsed % kEventPairs;
   HIP_TRY(hipEventRecord(c->ev[e][0], stream));
   hipError_t he = rtk::launch_render(p->accel == RT_ACCEL_BRUTE, p->use_photons != 0, p->collect_stats != 0, c->S, A,

@@ -45,6 +45,7 @@ struct RenderArgs {
   uint32_t n_tiles;
   uint32_t width, height, spp, s0, s1, mode, max_depth, seed, k, photons_requested;
   uint32_t flags;         // bit 0: shadow rays through the wave-level pool
+  uint32_t stackLevels;   // LDS traversal-stack entries per lane (BVH / kd depth + 1)
 };
 
 hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,

@@ -337,7 +337,7 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
 }
 
 // ---------------------------------------------------------------- shading
-constexpr int POOL_L = 4;                              // lights handled by the shadow-ray pool
+constexpr int POOL_L = 3;                              // lights handled by the shadow-ray pool
 constexpr int POOL_WORDS = 192 + POOL_L * 192 + 64 + 2 * POOL_L;  // per wave, 32-bit words
 
 RT_DEV uint32_t lanes_below(uint64_t m) {  // number of set bits of m below this lane
@@ -440,7 +440,7 @@ RT_DEV f3 shade_direct_pool(const DevScene& S, Rng& g, bool alive, f3 rayDir, co
       if (!T.live()) {
         const uint32_t r = head + lanes_below(idle);
         if (r < R) {
-          const uint32_t l = (r >= n) + (r >= 2 * n) + (r >= 3 * n);
+          const uint32_t l = (r >= n) + (r >= 2 * n);
           const uint32_t j = list[r - l * n];
           T.start(mk(vo[j], vo[64 + j], vo[128 + j]),
                   mk(vd[(l * 3 + 0) * 64 + j], vd[(l * 3 + 1) * 64 + j], vd[(l * 3 + 2) * 64 + j]), S.invBoxScale);
@@ -490,11 +490,11 @@ RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool 
 }
 
 template <bool PHOTON>
-RT_DEV Lds carve_lds(uint32_t* base) {
+RT_DEV Lds carve_lds(uint32_t* base, uint32_t levels = STACK) {
   Lds L;
   L.stack = base + threadIdx.x;
-  L.heapD = PHOTON ? reinterpret_cast<float*>(base + STACK * BLOCK) + threadIdx.x : nullptr;
-  L.heapI = PHOTON ? base + (STACK + KMAX) * BLOCK + threadIdx.x : nullptr;
+  L.heapD = PHOTON ? reinterpret_cast<float*>(base + levels * BLOCK) + threadIdx.x : nullptr;
+  L.heapI = PHOTON ? base + (levels + KMAX) * BLOCK + threadIdx.x : nullptr;
   return L;
 }
 
@@ -508,9 +508,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
                                                   unsigned long long* __restrict__ counters) {
   static_assert(BLOCK == 64, "the shadow-ray pool assumes one wave per workgroup");
   constexpr bool POOLED = !BRUTE && !PHOTON;
-  __shared__ uint32_t lds[(STACK + (PHOTON ? 2 * KMAX : 0)) * BLOCK + (POOLED ? POOL_WORDS : 0)];
-  const Lds L = carve_lds<PHOTON>(lds);
-  uint32_t* pool = lds + (STACK + (PHOTON ? 2 * KMAX : 0)) * BLOCK;
+  // dynamic LDS (render_lds_bytes): [levels][64] traversal stack, sized from the
+  // depth of THIS scene's trees so that LDS does not cap occupancy; then the photon
+  // k-heap or the shadow-ray pool
+  extern __shared__ uint32_t lds[];
+  const Lds L = carve_lds<PHOTON>(lds, A.stackLevels);
+  uint32_t* pool = lds + (A.stackLevels + (PHOTON ? 2 * KMAX : 0)) * BLOCK;
   const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   LaneStats st;
@@ -771,12 +774,16 @@ template <bool BRUTE, bool PHOTON>
 static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
                                  unsigned long long* counters, hipStream_t stream) {
   const uint32_t blocks = A.n_tiles;
+  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * KMAX : 0)) * BLOCK + ((!BRUTE && !PHOTON) ? POOL_WORDS : 0));
   if (blocks == 0) return hipSuccess;
   // MINW = 4 waves/SIMD (<= 128 VGPRs): measured +16 % over the unconstrained
   // 134-VGPR / 3-wave build on C2; the photon variant is LDS-limited to 2 anyway
-  constexpr int MINW = PHOTON ? 1 : 4;
-  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true, 1>), dim3(blocks), dim3(BLOCK), 0, stream, S, A, accum, counters);
-  else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false, MINW>), dim3(blocks), dim3(BLOCK), 0, stream, S, A, accum, counters);
+  // Occupancy target (waves per SIMD) measured on C2 with the LDS stack sized to the
+  // scene: 4 -> 12.0, 5 -> 12.4, 6 -> 11.8, 8 -> 10.8 Grays/s (beyond 5 the allocator
+  // spills inside the traversal loops).
+  constexpr int MINW = PHOTON ? 2 : (BRUTE ? 4 : 5);
+  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
+  else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   return hipGetLastError();
 }
 
