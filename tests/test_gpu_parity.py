@@ -342,7 +342,7 @@ def test_knn_golden_and_oracle(golden, cubes):
     for k, items in by_k.items():
         idx, dist, vis = ctx.knn(np.stack([it[0] for it in items]), k)
         for j, (_, visited, res) in enumerate(items):
-            assert vis[j] == visited
+            assert vis[j] <= visited  # the GPU walk skips subtrees that cannot change the result
             assert np.array_equal(bits(kp[idx[j]]), res[:, 0:3]) and np.array_equal(bits(kd_[idx[j]]), res[:, 3:6])
     rng = np.random.default_rng(3)
     qs = rng.uniform([-1.5, -1, -1.5], [1.5, 1.5, 1.5], (50000, 3)).astype(np.float32)
@@ -352,7 +352,8 @@ def test_knn_golden_and_oracle(golden, cubes):
     for k in (1, 2, 5, 10, 16):
         idx, dist, vis = ctx.knn(qs, k)
         ri, rd, rv = orc.knn(kd7, qs, k)
-        assert np.array_equal(idx, ri) and np.array_equal(bits(dist), bits(rd)) and np.array_equal(vis, rv)
+        assert np.array_equal(idx, ri) and np.array_equal(bits(dist), bits(rd))
+        assert (vis <= rv).all() and (k < 5 or vis.sum() < 0.6 * rv.sum())
     ctx.set_photons(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
 
 
@@ -372,5 +373,5 @@ def test_photon_frame_bit_exact_vs_oracle(kind, w, h, spp, mode, nph, k):
     ref_out, ref_acc, ref_st = orc.render(s, p, math_mode=orc.MATH_DET, bg=bg, ext_photons=ext)
     assert np.array_equal(bits(acc), bits(ref_acc))
     assert np.array_equal(bits(out), bits(ref_out))
-    assert (st.knn_queries, st.kd_visited, st.rays_shadow) == (ref_st.knn_queries, ref_st.kd_visited, 0)
+    assert (st.knn_queries, st.rays_shadow) == (ref_st.knn_queries, 0) and 0 < st.kd_visited <= ref_st.kd_visited
     ctx.close()
