@@ -79,12 +79,14 @@ constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane holds no live ray"
 // instead of the union of both (the single-loop form measured 34 % lane utilisation
 // on incoherent rays).  Between rounds a caller may hand finished lanes new rays
 // (shadow-ray pool below).
-template <bool ANY>
+constexpr int TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_MIXED = 2;  // MIXED: per-lane `anyHit` flag
+
+template <int MODE>
 struct Trav {
   f3 o, d, inv, oi;
   float best;
   uint32_t bestId;
-  bool found;
+  bool found, anyHit;
   int sp;
   int32_t cur;
   HitRec hit;
@@ -136,7 +138,7 @@ struct Trav {
         float u, v, t;
         if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t) &&
             t > 0.f) {
-          if (ANY) {
+          if (MODE == TRAV_ANY || (MODE == TRAV_MIXED && anyHit)) {
             found = true, stop = true;
             break;
           }
@@ -165,7 +167,7 @@ struct Trav {
 // `on` = this lane has a ray; lanes without one still take part in the wave loop.
 template <bool ANY, bool STATS>
 RT_DEV bool traverse(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
-  Trav<ANY> T;
+  Trav<ANY ? TRAV_ANY : TRAV_CLOSEST> T;
   T.idle();
   if (on) T.start(o, d, S.invBoxScale);
   while (__ballot(T.live()) != 0) T.template round<STATS>(S, stack, st);
@@ -347,7 +349,6 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
 
 // ---------------------------------------------------------------- shading
 constexpr int POOL_L = 3;                              // lights handled by the shadow-ray pool
-constexpr int POOL_WORDS = 192 + POOL_L * 192 + 64 + 2 * POOL_L;  // per wave, 32-bit words
 
 RT_DEV uint32_t lanes_below(uint64_t m) {  // number of set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -406,42 +407,73 @@ RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h
   return color;
 }
 
-// Renderer.cpp:49-60 for a whole wave at once.  The light samples of a vertex do
-// not depend on the shadow tests (the reference draws them unconditionally, in
-// light order), so all n_lights x (lanes with a vertex) shadow rays are known up
-// front.  They go into an LDS pool and the 64 lanes work through it as WORKERS:
-// a lane whose ray is decided fetches the next undecided one (__ballot + mbcnt
-// compaction, no atomics), instead of idling until the slowest of 64 rays ends —
-// any-hit rays end at very different times (occluded ones early).  Results come
-// back as one bit per (light, lane); the BSDF is then evaluated per pixel lane in
-// light order, i.e. the float sum is formed exactly as the sequential loop forms it.
-// Must be called in wave-uniform control flow (workgroup == one wave).
+// ---------------------------------------------------------------- vertex pool
+// Everything a path vertex sends out is known as soon as the vertex exists: the
+// n_lights shadow rays (Renderer.cpp:52-54: the light samples are drawn
+// unconditionally, in light order) AND the bounce ray (Renderer.cpp:164-166: the
+// hemisphere sample depends on the normal and the stream only).  So all
+// (n_lights + 1) x (lanes with a vertex) rays of a wave go into one LDS pool and the
+// 64 lanes work through it as WORKERS — a lane whose ray is decided fetches the next
+// undecided one (ballot + mbcnt compaction, no atomics) instead of idling until
+// the slowest of 64 rays ends.  Per pixel lane the pool holds: vertex position (3
+// words), the stream state before the light draws (1: a worker REPLAYS the two
+// draws of "its" light, so no direction is stored), bounce direction (3), which
+// the worker overwrites with the bounce hit record (5).  Shadow results are one
+// bit per (light, lane).  Arithmetic and draw order per pixel are exactly those of
+// the sequential code, so results are bit-identical.
+constexpr int VP_PT = 0, VP_RNG = 192, VP_BNC = 256, VP_LIST = 576, VP_RES = 640, VP_LT = 648;
+constexpr int VP_WORDS = VP_LT + 10 * POOL_L + 2;
+
+// LightSource::randAreaPosition (LightSource.h:46-49) minus the vertex, for light l
+// of the table {position, vertical, horizontal, side}, replaying the stream from the
+// state it had before the first light draw of this vertex.
+RT_DEV f3 light_dir_replay(const float* LT, uint32_t l, uint32_t state, f3 pt) {
+  Rng q{state};
+  for (uint32_t x = 0; x < l; x++) q.next(), q.next();
+  const float* t = LT + 10 * l;
+  const float side = t[9];
+  const float rh = q.uniformF(-side, side);
+  const float rv = q.uniformF(-side, side);
+  return mk(t[0], t[1], t[2]) + (rv * mk(t[3], t[4], t[5])) + (rh * mk(t[6], t[7], t[8])) - pt;
+}
+
+RT_DEV void vertex_pool_init(const DevScene& S, uint32_t* pool) {
+  const uint32_t lane = threadIdx.x;
+  float* LT = reinterpret_cast<float*>(pool + VP_LT);
+  if (lane < S.n_lights && lane < (uint32_t)POOL_L) {
+    const rt_light L = S.lights[lane];
+    for (int c = 0; c < 3; c++) LT[10 * lane + c] = L.position[c], LT[10 * lane + 3 + c] = L.vertical[c], LT[10 * lane + 6 + c] = L.horizontal[c];
+    LT[10 * lane + 9] = L.side;
+  }
+  __syncthreads();
+}
+
 template <bool STATS>
-RT_DEV f3 shade_direct_pool(const DevScene& S, Rng& g, bool alive, f3 rayDir, const HitRec& h, uint32_t* stack,
-                            uint32_t* pool, f3 hitNormal, f3 point, LaneStats& st) {
+RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, uint32_t rng0, f3 rayDir, uint32_t mesh, f3 hitNormal,
+                      f3 point, f3 bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
   const uint32_t lane = threadIdx.x, nl = S.n_lights;
-  float* vo = reinterpret_cast<float*>(pool);
-  float* vd = vo + 192;
-  uint32_t* list = pool + 192 + POOL_L * 192;
-  uint32_t* res = list + 64;
+  float* fp = reinterpret_cast<float*>(pool);
+  const float* LT = fp + VP_LT;
+  uint32_t* list = pool + VP_LIST;
+  uint32_t* res = pool + VP_RES;
   const uint64_t amask = __ballot(alive);
   const uint32_t n = (uint32_t)__popcll(amask);
   f3 color = mk(0.f, 0.f, 0.f);
+  nextFound = false;
   if (n == 0) return color;
   if (alive) {
-    vo[lane] = point.x, vo[64 + lane] = point.y, vo[128 + lane] = point.z;
-    for (uint32_t l = 0; l < nl; l++) {
-      const f3 tl = light_sample(g, S.lights[l]) - point;
-      vd[(l * 3 + 0) * 64 + lane] = tl.x, vd[(l * 3 + 1) * 64 + lane] = tl.y, vd[(l * 3 + 2) * 64 + lane] = tl.z;
-    }
+    fp[VP_PT + lane] = point.x, fp[VP_PT + 64 + lane] = point.y, fp[VP_PT + 128 + lane] = point.z;
+    pool[VP_RNG + lane] = rng0;
+    if (bounce) fp[VP_BNC + lane] = bdir.x, fp[VP_BNC + 64 + lane] = bdir.y, fp[VP_BNC + 128 + lane] = bdir.z;
     list[lanes_below(amask)] = lane;
     st.shadow += nl;
+    if (bounce) st.closest++;
   }
   if (lane < 2 * POOL_L) res[lane] = 0;
   __syncthreads();
-  const uint32_t R = n * nl;
-  uint32_t head = 0, myL = 0, myJ = 0;
-  Trav<true> T;
+  const uint32_t kinds = nl + (bounce ? 1u : 0u), R = n * kinds;
+  uint32_t head = 0, myK = 0, myJ = 0;
+  Trav<TRAV_MIXED> T;
   T.idle();
   for (;;) {
     const uint64_t idle = __ballot(!T.live());
@@ -449,11 +481,17 @@ RT_DEV f3 shade_direct_pool(const DevScene& S, Rng& g, bool alive, f3 rayDir, co
       if (!T.live()) {
         const uint32_t r = head + lanes_below(idle);
         if (r < R) {
-          const uint32_t l = (r >= n) + (r >= 2 * n);
-          const uint32_t j = list[r - l * n];
-          T.start(mk(vo[j], vo[64 + j], vo[128 + j]),
-                  mk(vd[(l * 3 + 0) * 64 + j], vd[(l * 3 + 1) * 64 + j], vd[(l * 3 + 2) * 64 + j]), S.invBoxScale);
-          myL = l, myJ = j;
+          // the bounce rays (closest hit: the longest walks) are handed out first
+          uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);  // r / n for kinds <= POOL_L + 1
+          const uint32_t j = list[r - k * n];
+          k = bounce ? (k == 0 ? nl : k - 1) : k;
+          const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
+          f3 dj;
+          if (k < nl) dj = light_dir_replay(LT, k, pool[VP_RNG + j], pj);
+          else dj = mk(fp[VP_BNC + j], fp[VP_BNC + 64 + j], fp[VP_BNC + 128 + j]);
+          T.start(pj, dj, S.invBoxScale);
+          T.anyHit = k < nl;
+          myK = k, myJ = j;
         }
       }
       head += (uint32_t)__popcll(idle);
@@ -461,19 +499,34 @@ RT_DEV f3 shade_direct_pool(const DevScene& S, Rng& g, bool alive, f3 rayDir, co
     if (__ballot(T.live()) == 0) break;
     const bool was = T.live();
     T.template round<STATS>(S, stack, st);
-    if (was && !T.live() && T.found) atomicOr(&res[myL * 2 + (myJ >> 5)], 1u << (myJ & 31));
+    if (was && !T.live()) {
+      if (myK < nl) {
+        if (T.found) atomicOr(&res[myK * 2 + (myJ >> 5)], 1u << (myJ & 31));
+      } else {  // bounce result replaces the bounce direction of pixel lane myJ
+        fp[VP_BNC + myJ] = T.found ? T.hit.t : -1.f;
+        fp[VP_BNC + 64 + myJ] = T.hit.u, fp[VP_BNC + 128 + myJ] = T.hit.v;
+        pool[VP_BNC + 192 + myJ] = T.hit.id, pool[VP_BNC + 256 + myJ] = T.hit.mesh;
+      }
+    }
   }
   __syncthreads();
   if (alive) {
-    const rt_material mat = S.mats[h.mesh];
+    const rt_material mat = S.mats[mesh];
     for (uint32_t l = 0; l < nl; l++) {
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
-      const f3 toLight = mk(vd[(l * 3 + 0) * 64 + lane], vd[(l * 3 + 1) * 64 + lane], vd[(l * 3 + 2) * 64 + lane]);
+      const f3 toLight = light_dir_replay(LT, l, rng0, point);
       const f3 bsdf = bsdf_eval(mat, hitNormal, toLight, -rayDir);
       const f3 radiance = light_eval(S.lights[l], point);
       color = color + radiance * bsdf;
     }
+    if (bounce) {
+      const float t = fp[VP_BNC + lane];
+      nextFound = t > 0.f;
+      next.t = t, next.u = fp[VP_BNC + 64 + lane], next.v = fp[VP_BNC + 128 + lane];
+      next.id = pool[VP_BNC + 192 + lane], next.mesh = pool[VP_BNC + 256 + lane];
+    }
   }
+  __syncthreads();  // the pool is rewritten by the next vertex
   return color;
 }
 
@@ -535,6 +588,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
     float4 sum = inImage ? accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool pooled = POOLED && (A.flags & 1u) && S.n_lights <= (uint32_t)POOL_L;
     const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
+    if (pooled) vertex_pool_init(S, pool);
     for (uint32_t i = A.s0; i < A.s1; i++) {
       Rng g{rt_stream_seed(A.seed, RT_STREAM_PIXEL, pix, i)};
       float sx, sy;
@@ -543,6 +597,37 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
       camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
       f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
       bool primary = true, alive = inImage;
+      if (pooled) {
+        // primary ray (coherent: traced in lock step), then one pool per vertex
+        HitRec h;
+        if (alive) st.closest++;
+        const bool hit0 = cast<false, false, STATS>(S, alive, o, d, L.stack, h, st);
+        if (alive && !hit0) primary = false, alive = false;
+        for (int depth = 0; depth < nvert; depth++) {
+          if (__ballot(alive) == 0) break;
+          const bool bounce = A.mode == RT_MODE_PATH && depth + 1 < nvert;  // wave-uniform
+          f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, bdir = nrm;
+          const uint32_t rng0 = g.s;
+          if (alive) {
+            vertex_setup(S, h, nrm, pt);
+            for (uint32_t l = 0; l < 2 * S.n_lights; l++) g.next();  // the light draws (replayed in the pool)
+            // Renderer.cpp:164: drawn after every shaded vertex; after the LAST one the
+            // reference draws it too but never traces it, and the stream ends there
+            if (bounce) bdir = hemisphere_sample(g, nrm);
+          }
+          HitRec nh;
+          bool nfound;
+          const f3 c = vertex_pool<STATS>(S, alive, bounce, rng0, d, h.mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
+          if (alive) {
+            if (depth == 0) c0 = c;
+            else if (depth == 1) c1 = c;
+            else if (depth == 2) c2 = c;
+            else c3 = c;
+            d = bdir, h = nh;
+            if (!nfound) alive = false;
+          }
+        }
+      } else
       for (int depth = 0; depth < nvert; depth++) {
         HitRec h;
         if (alive) st.closest++;
@@ -556,8 +641,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
         if (alive) vertex_setup(S, h, nrm, pt);
         if (PHOTON) {
           if (alive) c = shade_photon<STATS>(S, A, d, h, L, nrm, pt, st);
-        } else if (pooled) {
-          c = shade_direct_pool<STATS>(S, g, alive, d, h, L.stack, pool, nrm, pt, st);
         } else {
           if (alive) c = shade_direct_seq<BRUTE, STATS>(S, g, d, h, L.stack, nrm, pt, st);
         }
@@ -784,7 +867,7 @@ template <bool BRUTE, bool PHOTON>
 static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
                                  unsigned long long* counters, hipStream_t stream) {
   const uint32_t blocks = A.n_tiles;
-  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + ((!BRUTE && !PHOTON) ? POOL_WORDS : 0));
+  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + ((!BRUTE && !PHOTON) ? VP_WORDS : 0));
   if (blocks == 0) return hipSuccess;
   // MINW = 4 waves/SIMD (<= 128 VGPRs): measured +16 % over the unconstrained
   // 134-VGPR / 3-wave build on C2; the photon variant is LDS-limited to 2 anyway
