@@ -139,11 +139,20 @@ def main():
     kernel_ms, launches = ctx.profile_collect()
 
     # roofline of the dominant kernel (k_render) on THIS rank: algorithmic bytes per
-    # launch (64 B per BVH node record fetched + 48 B per triangle record
-    # tested + 16 B per pixel-sample for the accumulator, + 32 B per kd node visited)
-    alg_bytes = 64 * local_counts[2] + 48 * local_counts[3] + 16 * local_counts[4] + 32 * local_counts[6]
+    # launch = bytes per unit x units of this launch: one BVH node record
+    # per node fetched (32 B: the packed f16 node this build traverses; §8d priced a
+    # 64-B float node), 48 B per triangle record tested, 16 B per pixel-sample for the
+    # accumulator, 32 B (position + direction) per kd node visited
+    alg_bytes = 32 * local_counts[2] + 48 * local_counts[3] + 16 * local_counts[4] + 32 * local_counts[6]
     avg_ms = kernel_ms / max(launches, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+
+    # HBM traffic of the same launch from PMC counters (tools/traffic.sh, committed under
+    # profiles/): FETCH_SIZE (doubled, gfx950 correction) + WRITE_SIZE
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.workload)
+    if os.path.exists(tpath) and not args.spp and world == 1 and args.accel == "bvh":
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
 
     if rank == 0:
         res = {
@@ -160,12 +169,13 @@ def main():
                        "rays_per_frame": rays_per_frame, "samples_per_frame": tot[4],
                        "knn_queries_per_frame": tot[5]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_render", "kernel_ms_avg": avg_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "nodes_per_ray": tot[2] / max(rays_per_frame, 1), "tris_per_ray": tot[3] / max(rays_per_frame, 1),
-                         "note": "scene is %.2f MB: cache-resident, achieved counts algorithmic not HBM bytes"
-                                 % ((64 * ctx.bvh_info().n_nodes + 48 * scene.desc.n_triangles) / 1e6)},
+                         "note": "scene is %.2f MB (L2/Infinity-Cache resident): achieved is the ALGORITHMIC byte rate, "
+                                 "served mostly by caches; traffic = measured HBM bytes per launch"
+                                 % ((32 * ctx.bvh_info().n_nodes + 48 * scene.desc.n_triangles) / 1e6)},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(kind, mode, spp)

@@ -134,7 +134,7 @@ int check_params(const rt_ctx* c, const rt_params* p) {
     return fail(RT_ERR_UNSUPPORTED,
                 "rng_mode legacy is one global serial engine (reference LightSource.h:6) and cannot run in "
                 "parallel; the GPU path implements RT_RNG_PIXEL only");
-  if (p->max_depth < 1 || p->max_depth > 4) return fail(RT_ERR_UNSUPPORTED, "max_depth must be in 1..4");
+  if (p->max_depth < 1 || p->max_depth > 3) return fail(RT_ERR_UNSUPPORTED, "max_depth must be in 1..3");
   if (p->world > 1 && p->rank >= p->world) return fail(RT_ERR_INVALID, "rank %u >= world %u", p->rank, p->world);
   if (p->tile % 8 != 0) return fail(RT_ERR_INVALID, "tile must be a multiple of 8");
   if (p->spp_count && (uint64_t)p->spp_begin + p->spp_count > p->spp)

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
       jitter_sample(g, (int)i, (int)A.spp, sx, sy);
       f3 o, d;
       camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
-      f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
+      f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0;
       bool primary = true, alive = inImage;
       if (pooled) {
         // primary ray (coherent: traced in lock step), then one pool per vertex
@@ -621,8 +621,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
           if (alive) {
             if (depth == 0) c0 = c;
             else if (depth == 1) c1 = c;
-            else if (depth == 2) c2 = c;
-            else c3 = c;
+            else c2 = c;
             d = bdir, h = nh;
             if (!nfound) alive = false;
           }
@@ -647,8 +646,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
         if (alive) {
           if (depth == 0) c0 = c;
           else if (depth == 1) c1 = c;
-          else if (depth == 2) c2 = c;
-          else c3 = c;
+          else c2 = c;
         }
         if (A.mode != RT_MODE_PATH) break;
         if (alive) {
@@ -656,8 +654,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
           o = pt;
         }
       }
-      // calculateColorPath returns c0 + (c1 + (c2 + (c3 + 0)))
-      const f3 total = c0 + (c1 + (c2 + (c3 + mk(0.f, 0.f, 0.f))));
+      // calculateColorPath returns c0 + (c1 + (c2 + 0)) for finalDepth <= 3
+      const f3 total = c0 + (c1 + (c2 + mk(0.f, 0.f, 0.f)));
       sum.x += clamp01(total.x);
       sum.y += clamp01(total.y);
       sum.z += clamp01(total.z);
@@ -875,7 +873,9 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   // scene: 4 -> 12.0, 5 -> 12.4, 6 -> 11.8, 8 -> 10.8 Grays/s (beyond 5 the allocator
   // spills inside the traversal loops).
   constexpr int MINW = PHOTON ? 2 : (BRUTE ? 4 : 5);
+  static const int minw = getenv("RT_MINWAVES") ? atoi(getenv("RT_MINWAVES")) : MINW;
   if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
+  else if (!PHOTON && !BRUTE && minw == 4) hipLaunchKernelGGL((k_render<false, false, false, 4>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   return hipGetLastError();
 }

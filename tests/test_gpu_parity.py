@@ -300,7 +300,7 @@ def test_frame_is_deterministic_and_split_invariant():
 
 def test_parameter_validation(cubes):
     s, ctx = cubes
-    for kw, code in ((dict(rng_mode=pyrt.RNG_LEGACY), 4), (dict(max_depth=0), 4), (dict(max_depth=5), 4),
+    for kw, code in ((dict(rng_mode=pyrt.RNG_LEGACY), 4), (dict(max_depth=0), 4), (dict(max_depth=4), 4),
                      (dict(use_photons=1, k=5, photons_requested=100), 5), (dict(rank=2, world=2), 1),
                      (dict(tile=12), 1), (dict(spp_begin=3, spp_count=4), 1)):
         with pytest.raises(pyrt.RtError) as e:
@@ -374,4 +374,32 @@ def test_photon_frame_bit_exact_vs_oracle(kind, w, h, spp, mode, nph, k):
     assert np.array_equal(bits(acc), bits(ref_acc))
     assert np.array_equal(bits(out), bits(ref_out))
     assert (st.knn_queries, st.rays_shadow) == (ref_st.knn_queries, 0) and 0 < st.kd_visited <= ref_st.kd_visited
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind,n", [("hires", 300000), ("stress", 4000)])
+def test_bvh_equals_exhaustive_loop_on_big_scenes(kind, n):
+    """11.7k-triangle and 1M-triangle scenes: every field of every hit record from the
+    BVH kernel equals the exhaustive (reference-order) kernel's."""
+    s = pyrt.Scene(kind, 256, 256)
+    ctx = pyrt.Context(s)
+    rays = _ray_batch(s, n, 4321)
+    a = ctx.trace(rays, pyrt.ACCEL_BRUTE)
+    b = ctx.trace(rays, pyrt.ACCEL_BVH)
+    assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BRUTE, pyrt.TRACE_ANY)["hit"], ctx.trace(rays, pyrt.ACCEL_BVH, pyrt.TRACE_ANY)["hit"])
+    bi = ctx.bvh_info()
+    assert bi.max_depth < 32
+    ctx.close()
+
+
+def test_stress_frame_bvh_equals_brute_on_a_tile():
+    """C5 scene, a 16x16-pixel corner rendered with the BVH and with the exhaustive loop."""
+    s = pyrt.Scene("stress", 16, 16)
+    ctx = pyrt.Context(s)
+    p = pyrt.make_params(16, 16, 2, seed=3)
+    _, a, _ = ctx.render(p)
+    p.accel = pyrt.ACCEL_BRUTE
+    _, b, _ = ctx.render(p)
+    assert np.array_equal(bits(a), bits(b))
     ctx.close()
