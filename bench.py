@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accel", default="bvh", choices=["bvh", "brute"])
     ap.add_argument("--leaf", type=int, default=0, help="BVH leaf size override (debug)")
+    ap.add_argument("--lpp", type=int, default=0, help="samples of a pixel per wave override (debug)")
     args = ap.parse_args()
 
     import torch
@@ -99,7 +100,7 @@ def main():
         kp, kd_, _ = pyrt.kd_order(pos, dr, wt)
         ctx.set_photons(kp, kd_)
     params = pyrt.make_params(w, h, spp, mode=mode, seed=1, accel=accel, rank=rank, world=world, tile=32,
-                              use_photons=use_ph, k=k, photons_requested=nph)
+                              use_photons=use_ph, k=k, photons_requested=nph, lanes_per_pixel=args.lpp)
 
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
     bg = torch.from_numpy(pyrt.background(w, h)).to(dev)

@@ -103,7 +103,9 @@ typedef struct rt_params {
                                  tiles t with owner(t) == rank                 */
   uint32_t tile;              /* ownership granule in pixels (multiple of 8)   */
   uint32_t collect_stats;     /* 1: also count BVH nodes / triangle tests      */
-  uint32_t reserved[7];
+  uint32_t reserved[7];       /* [0]: samples of a pixel one wave integrates side by
+                                 side (power of two <= 64; 0 = chosen from the grid
+                                 size).  Never changes the result, only the schedule. */
 } rt_params;
 
 typedef struct rt_stats {

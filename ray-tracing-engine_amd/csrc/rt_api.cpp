@@ -62,11 +62,18 @@ int upload(T** dptr, const void* src, size_t count) {
 }
 
 struct TileKey {
-  uint32_t w = 0, h = 0, rank = 0, world = 0, tile = 0;
+  uint32_t w = 0, h = 0, rank = 0, world = 0, tile = 0, sshift = 0;
   bool operator==(const TileKey& o) const {
-    return w == o.w && h == o.h && rank == o.rank && world == o.world && tile == o.tile;
+    return w == o.w && h == o.h && rank == o.rank && world == o.world && tile == o.tile && sshift == o.sshift;
   }
 };
+
+// A wave integrates (64 >> sshift) pixels x (1 << sshift) samples at a time.  Pixel
+// footprint of one wave for sshift = 0..6: 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1.
+void wave_tile_shape(uint32_t sshift, uint32_t& tw, uint32_t& th) {
+  static const uint32_t W[7] = {8, 8, 4, 4, 2, 2, 1}, H[7] = {8, 4, 4, 2, 2, 1, 1};
+  tw = W[sshift], th = H[sshift];
+}
 
 constexpr int kEventPairs = 256;
 
@@ -100,18 +107,48 @@ int upload_owned(rt_ctx* c, const T** field, const void* src, size_t count) {
   return RT_OK;
 }
 
-int ensure_tiles(rt_ctx* c, const rt_params* p) {
+// How many samples of a pixel one wave integrates side by side.  A pixel's float
+// sum must be formed in sample order, but only the ADDS are ordered: the samples
+// themselves are independent streams, so the 64 lanes of a wave can hold
+// (pixel, sample) pairs and hand their results to the pixel's owner lane, which adds
+// them in order.  More samples per wave = more, shorter work items: the grid no longer
+// quantises into ~3 rounds of 16k tile-sized items, and a rank that owns 1/8 of the
+// pixels still fills the GPU.
+uint32_t choose_sshift(const rt_params* p, uint32_t spp_count) {
+  if (p->reserved[0]) {  // explicit lanes-per-pixel (tests, experiments)
+    uint32_t s = 0;
+    while ((1u << (s + 1)) <= p->reserved[0] && s < 6) ++s;
+    return s;
+  }
+  const uint64_t world = p->world ? p->world : 1;
+  const uint64_t pixels = (uint64_t)p->width * p->height / world;
+  // measured on C2 (1024^2 x 128 spp), samples per wave 1/2/4/8/16/64:
+  // 12.3 / 12.8 / 13.4 / 13.6 / 13.7 / 13.6 Grays/s -> aim for >= 32 rounds of a
+  // 256-CU x 16-wave chip
+  const uint64_t target = 32ull * 256 * 16;
+  uint32_t s = 0;
+  while (s < 6 && (pixels << s) / 64 < target && (2u << s) <= spp_count) ++s;
+  return s;
+}
+
+int ensure_tiles(rt_ctx* c, const rt_params* p, uint32_t sshift) {
   TileKey k;
   k.w = p->width, k.h = p->height, k.rank = p->rank, k.world = p->world ? p->world : 1;
   k.tile = p->tile ? p->tile : 8;
+  k.sshift = sshift;
   if (c->dTiles && k == c->tileKey) return RT_OK;
   std::vector<uint32_t> tiles;
-  const uint32_t tx8 = (k.w + 7) / 8, ty8 = (k.h + 7) / 8;
-  for (uint32_t ty = 0; ty < ty8; ++ty)
-    for (uint32_t tx = 0; tx < tx8; ++tx) {
-      const uint32_t ox = tx * 8 / k.tile, oy = ty * 8 / k.tile;
+  uint32_t tw, th;
+  wave_tile_shape(sshift, tw, th);
+  // enumerate 8x8 granules row-major and the wave tiles inside each granule, so that
+  // consecutive waves touch neighbouring pixels
+  const uint32_t gx = (k.w + 7) / 8, gy = (k.h + 7) / 8;
+  for (uint32_t y8 = 0; y8 < gy; ++y8)
+    for (uint32_t x8 = 0; x8 < gx; ++x8) {
+      const uint32_t ox = x8 * 8 / k.tile, oy = y8 * 8 / k.tile;
       if (k.world > 1 && (ox + oy) % k.world != k.rank) continue;
-      tiles.push_back(tx | (ty << 16));
+      for (uint32_t y = y8 * 8; y < y8 * 8 + 8 && y < k.h; y += th)
+        for (uint32_t x = x8 * 8; x < x8 * 8 + 8 && x < k.w; x += tw) tiles.push_back(x | (y << 16));
     }
   if (c->dTiles) {
     HIP_TRY(hipFree(c->dTiles));
@@ -126,7 +163,7 @@ int ensure_tiles(rt_ctx* c, const rt_params* p) {
 
 int check_params(const rt_ctx* c, const rt_params* p) {
   if (!p) return fail(RT_ERR_INVALID, "params is null");
-  if (p->width == 0 || p->height == 0 || p->width > 8 * 65535u || p->height > 8 * 65535u)
+  if (p->width == 0 || p->height == 0 || p->width > 65535u || p->height > 65535u)
     return fail(RT_ERR_INVALID, "image size %ux%u out of range", p->width, p->height);
   if (p->spp == 0) return fail(RT_ERR_INVALID, "spp must be >= 1");
   if (p->mode != RT_MODE_RAY && p->mode != RT_MODE_PATH) return fail(RT_ERR_INVALID, "mode must be 0 or 1");
@@ -163,9 +200,13 @@ int read_counters(rt_ctx* c, rt_stats* st) {
 
 // Launch the integrate kernel for p on `stream`, bracketed by an event pair.
 int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stream, int* evIndex) {
-  int rc = ensure_tiles(c, p);
+  const uint32_t sppCount = p->spp_count ? p->spp_count : p->spp;
+  const uint32_t sshift = choose_sshift(p, sppCount);
+  int rc = ensure_tiles(c, p, sshift);
   if (rc != RT_OK) return rc;
   rtk::RenderArgs A;
+  A.sshift = sshift;
+  wave_tile_shape(sshift, A.tileW, A.tileH);
   A.tiles = c->dTiles, A.n_tiles = c->nTiles;
   A.width = p->width, A.height = p->height, A.spp = p->spp;
   A.s0 = p->spp_count ? p->spp_begin : 0;

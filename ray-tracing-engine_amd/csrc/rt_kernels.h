@@ -41,11 +41,13 @@ struct DevScene {
 };
 
 struct RenderArgs {
-  const uint32_t* tiles;  // owned 8x8 tiles, x8 | y8 << 16
+  const uint32_t* tiles;  // owned wave tiles: x0 | y0 << 16 (pixels, top-left corner)
   uint32_t n_tiles;
   uint32_t width, height, spp, s0, s1, mode, max_depth, seed, k, photons_requested;
   uint32_t flags;         // bit 0: shadow rays through the wave-level pool
   uint32_t stackLevels;   // LDS traversal-stack entries per lane (BVH / kd depth + 1)
+  uint32_t sshift;        // a wave = (64 >> sshift) pixels x (1 << sshift) samples side by side
+  uint32_t tileW, tileH;  // pixel footprint of one wave (tileW * tileH == 64 >> sshift)
 };
 
 hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,

@@ -577,26 +577,35 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
   extern __shared__ uint32_t lds[];
   const Lds L = carve_lds<PHOTON>(lds, A.stackLevels, A.k);
   uint32_t* pool = lds + (A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK;
+  float* ex = reinterpret_cast<float*>(pool + (POOLED ? VP_WORDS : 0));  // [4][64] sample results
   const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   LaneStats st;
   if (wave < A.n_tiles) {
+    // lane = (pixel pl of the wave tile, sample slot sj): the wave integrates
+    // S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side
     const uint32_t tile = A.tiles[wave];
-    const uint32_t px = (tile & 0xffffu) * 8u + (lane & 7u), py = (tile >> 16) * 8u + (lane >> 3);
+    const uint32_t S_ = 1u << A.sshift, P_ = 64u >> A.sshift;
+    const uint32_t pl = lane & (P_ - 1u), sj = lane >> (6u - A.sshift);
+    const uint32_t wsh = (uint32_t)__builtin_ctz(A.tileW);
+    const uint32_t px = (tile & 0xffffu) + (pl & (A.tileW - 1u)), py = (tile >> 16) + (pl >> wsh);
     const bool inImage = px < A.width && py < A.height;
+    const bool owner = inImage && sj == 0;  // adds this pixel's samples, in order
     const uint32_t pix = inImage ? py * A.width + px : 0u;
-    float4 sum = inImage ? accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sum = owner ? accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool pooled = POOLED && (A.flags & 1u) && S.n_lights <= (uint32_t)POOL_L;
     const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
     if (pooled) vertex_pool_init(S, pool);
-    for (uint32_t i = A.s0; i < A.s1; i++) {
+    for (uint32_t base = A.s0; base < A.s1; base += S_) {
+      const uint32_t i = base + sj;
+      const bool active = inImage && i < A.s1;
       Rng g{rt_stream_seed(A.seed, RT_STREAM_PIXEL, pix, i)};
       float sx, sy;
       jitter_sample(g, (int)i, (int)A.spp, sx, sy);
       f3 o, d;
       camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
       f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0;
-      bool primary = true, alive = inImage;
+      bool primary = true, alive = active;
       if (pooled) {
         // primary ray (coherent: traced in lock step), then one pool per vertex
         HitRec h;
@@ -656,12 +665,29 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
       }
       // calculateColorPath returns c0 + (c1 + (c2 + 0)) for finalDepth <= 3
       const f3 total = c0 + (c1 + (c2 + mk(0.f, 0.f, 0.f)));
-      sum.x += clamp01(total.x);
-      sum.y += clamp01(total.y);
-      sum.z += clamp01(total.z);
-      if (primary) sum.w += 1.f;
+      const float r0 = clamp01(total.x), r1 = clamp01(total.y), r2 = clamp01(total.z);
+      if (A.sshift == 0) {
+        if (active) {
+          sum.x += r0, sum.y += r1, sum.z += r2;
+          if (primary) sum.w += 1.f;
+        }
+      } else {
+        // hand the sample to the pixel's owner lane, which adds samples base.. in order
+        // (Renderer.cpp:258: updateImage += colorResponse, i = 0..N-1)
+        ex[lane] = r0, ex[64 + lane] = r1, ex[128 + lane] = r2, ex[192 + lane] = primary ? 1.f : 0.f;
+        __syncthreads();
+        if (owner) {
+          const uint32_t cnt = A.s1 - base < S_ ? A.s1 - base : S_;
+          for (uint32_t jj = 0; jj < cnt; jj++) {
+            const uint32_t q = jj * P_ + pl;
+            sum.x += ex[q], sum.y += ex[64 + q], sum.z += ex[128 + q];
+            sum.w += ex[192 + q];  // adds 1.0 or an exact 0.0
+          }
+        }
+        __syncthreads();
+      }
     }
-    if (inImage) accum[pix] = sum;
+    if (owner) accum[pix] = sum;
   }
   flush_stats(st, counters, STATS);
 }
@@ -865,17 +891,15 @@ template <bool BRUTE, bool PHOTON>
 static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
                                  unsigned long long* counters, hipStream_t stream) {
   const uint32_t blocks = A.n_tiles;
-  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + ((!BRUTE && !PHOTON) ? VP_WORDS : 0));
+  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + ((!BRUTE && !PHOTON) ? VP_WORDS : 0) + 256);
   if (blocks == 0) return hipSuccess;
   // MINW = 4 waves/SIMD (<= 128 VGPRs): measured +16 % over the unconstrained
   // 134-VGPR / 3-wave build on C2; the photon variant is LDS-limited to 2 anyway
-  // Occupancy target (waves per SIMD) measured on C2 with the LDS stack sized to the
-  // scene: 4 -> 12.0, 5 -> 12.4, 6 -> 11.8, 8 -> 10.8 Grays/s (beyond 5 the allocator
-  // spills inside the traversal loops).
-  constexpr int MINW = PHOTON ? 2 : (BRUTE ? 4 : 5);
-  static const int minw = getenv("RT_MINWAVES") ? atoi(getenv("RT_MINWAVES")) : MINW;
+  // Occupancy target (waves per SIMD), measured on C2 with the LDS stack sized to the
+  // scene and 16 samples per wave: 4 -> 13.9, 5 -> 13.7 Grays/s; 6 and 8 lose 5-15 %
+  // (the allocator spills inside the traversal loops).
+  constexpr int MINW = PHOTON ? 2 : 4;
   if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
-  else if (!PHOTON && !BRUTE && minw == 4) hipLaunchKernelGGL((k_render<false, false, false, 4>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   return hipGetLastError();
 }
