@@ -37,6 +37,7 @@ struct DevScene {
   const float4* phDir;     // income direction xyz + weight
   uint32_t n_tris, n_nodes, n_lights, n_photons;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
+  uint32_t leafT;          // Trav::round leaves its descent when fewer lanes than this still descend
   rt_camera cam;
 };
 

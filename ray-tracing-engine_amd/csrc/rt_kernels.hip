@@ -132,8 +132,11 @@ struct Trav {
       } else {
         cur = TERM;
       }
+      // leave the descent early once only a few lanes are still descending: they
+      // sit out one leaf phase (masked) instead of making everyone else wait for them
+      if (__popcll(__ballot(cur >= 0)) < (int)S.leafT) break;
     }
-    if (cur != TERM) {
+    if (cur < 0 && cur != TERM) {
       const uint32_t code = ~(uint32_t)cur;
       const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
       bool stop = false;
