@@ -139,24 +139,17 @@ struct Trav {
     if (cur < 0 && cur != TERM) {
       const uint32_t code = ~(uint32_t)cur;
       const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-      bool stop = false;
-      for (uint32_t i = 0; i < cnt; i++) {
-        const float4* r = S.tris + 3 * (size_t)(first + i);
-        const float4 q0 = r[0], q1 = r[1], q2 = r[2];
-        if (STATS) st.tris++;
-        float u, v, t;
-        if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t) &&
-            t > 0.f) {
-          if (MODE == TRAV_ANY || (MODE == TRAV_MIXED && anyHit)) {
-            found = true, stop = true;
-            break;
-          }
-          const uint32_t id = __float_as_uint(q2.y);
-          if (t < best || (t == best && id < bestId)) {
-            best = t, bestId = id, found = true;
-            hit.t = t, hit.u = u, hit.v = v, hit.id = id, hit.mesh = __float_as_uint(q2.z);
-          }
-        }
+      // leaves hold 1..leaf_max (default 2) records: the first two are tested in
+      // straight-line code with both records' loads in flight together
+      const float4* r = S.tris + 3 * (size_t)first;
+      const uint32_t second = cnt > 1 ? 3u : 0u;  // a 1-triangle leaf re-reads its only record
+      const float4 a0 = r[0], a1 = r[1], a2 = r[2];
+      const float4 b0 = r[second + 0], b1 = r[second + 1], b2 = r[second + 2];
+      bool stop = test_record<STATS>(a0, a1, a2, st);
+      if (!stop && cnt > 1) stop = test_record<STATS>(b0, b1, b2, st);
+      for (uint32_t i = 2; i < cnt && !stop; i++) {
+        const float4* q = S.tris + 3 * (size_t)(first + i);
+        stop = test_record<STATS>(q[0], q[1], q[2], st);
       }
       if (stop || sp == 0) {
         cur = TERM;
@@ -165,6 +158,26 @@ struct Trav {
         cur = (int32_t)stack[sp * BLOCK];
       }
     }
+  }
+
+  // Ray.cpp:9-24 on one 48-B record + the acceptance rule of RayTracer.h:40.
+  // Returns true when the ray is decided (any-hit rays only).
+  template <bool STATS>
+  RT_DEV bool test_record(const float4& q0, const float4& q1, const float4& q2, LaneStats& st) {
+    if (STATS) st.tris++;
+    float u, v, t;
+    if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t) && t > 0.f) {
+      if (MODE == TRAV_ANY || (MODE == TRAV_MIXED && anyHit)) {
+        found = true;
+        return true;
+      }
+      const uint32_t id = __float_as_uint(q2.y);
+      if (t < best || (t == best && id < bestId)) {
+        best = t, bestId = id, found = true;
+        hit.t = t, hit.u = u, hit.v = v, hit.id = id, hit.mesh = __float_as_uint(q2.z);
+      }
+    }
+    return false;
   }
 };
 

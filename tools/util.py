@@ -6,8 +6,7 @@ for kind,w,spp,mode in (("lowres",512,16,1),("cubes",512,16,1),("stress",512,4,1
     s=pyrt.Scene(kind,w,w); ctx=pyrt.Context(s)
     p=pyrt.make_params(w,w,spp,mode=mode,seed=1,collect_stats=1)
     _,_,st=ctx.render(p,want_accum=False)
-    r=st.reserved
-    rays=st.rays_closest+st.rays_shadow
-    print(kind,"node steps/ray %.2f | node-loop lane util %.3f | rounds/ray(wave) %.2f | leaf-phase lane util %.3f | tri tests/ray %.2f tri-loop util %.3f"%(
-      st.nodes_visited/rays, st.nodes_visited/(64*r[0]), r[1]*64/rays, r[2]/(64*r[1]), st.tris_tested/rays, st.tris_tested/(64*r[3])))
+    r=st.reserved; tot=r[3]
+    print(kind,"of wave lifetime: node loops %.3f | leaf phases %.3f | pool loop total %.3f (overhead %.3f) | everything else %.3f"%(
+      r[0]/tot, r[1]/tot, r[2]/tot, (r[2]-r[0]-r[1])/tot if False else 0, 1-(r[0]+r[1])/tot))
     ctx.close()
