@@ -34,6 +34,8 @@ struct Prim {
   uint32_t id;
 };
 
+constexpr uint32_t kSweepMax = 4096;  // 32768 built a slightly worse C4 tree (10.3 vs 10.0 nodes/ray)
+
 struct Builder {
   const rt_scene_desc& sc;
   std::vector<Prim> prims;
@@ -74,6 +76,36 @@ struct Builder {
     // depth budget: once the remaining levels are only just enough for a
     // balanced subdivision, stop trusting SAH
     if (depth + 1 + levelsFor((n + 1) / 2) + 2 >= kMaxDepth) return medianSplit();
+
+    // small ranges: exact SAH sweep over all three axes (every split position)
+    if (n <= kSweepMax) {
+      float bestCostS = std::numeric_limits<float>::infinity();
+      int bestAx = -1;
+      uint32_t bestPos = 0;
+      std::vector<float> rightArea(n);
+      for (int ax = 0; ax < 3; ++ax) {
+        std::sort(prims.begin() + b, prims.begin() + e,
+                  [ax](const Prim& p, const Prim& q) { return p.c[ax] < q.c[ax] || (p.c[ax] == q.c[ax] && p.id < q.id); });
+        Box acc;
+        acc.reset();
+        for (uint32_t i = n; i-- > 1;) {
+          acc.grow(prims[b + i].box);
+          rightArea[i] = acc.halfArea();
+        }
+        acc.reset();
+        for (uint32_t i = 1; i < n; ++i) {
+          acc.grow(prims[b + i - 1].box);
+          const float cost = acc.halfArea() * std::ceil(i / static_cast<float>(leafMax)) +
+                             rightArea[i] * std::ceil((n - i) / static_cast<float>(leafMax));
+          if (cost < bestCostS) bestCostS = cost, bestAx = ax, bestPos = i;
+        }
+      }
+      if (bestAx < 0) return medianSplit();
+      const int ax = bestAx;
+      std::sort(prims.begin() + b, prims.begin() + e,
+                [ax](const Prim& p, const Prim& q) { return p.c[ax] < q.c[ax] || (p.c[ax] == q.c[ax] && p.id < q.id); });
+      return b + bestPos;
+    }
 
     constexpr int NB = 16;
     float bestCost = std::numeric_limits<float>::infinity();
