@@ -82,7 +82,11 @@ def main():
     import pyrt
     from pyrt import dist as rdist
 
-    rank, world, local = rdist.init_from_env("nccl")
+    # RT_DIST_BACKEND=gloo + RT_SHARE_GPU=1: rehearsal of the N-rank flow on ONE GPU
+    backend = os.environ.get("RT_DIST_BACKEND", "nccl")
+    rank, world, local = rdist.init_from_env(backend)
+    if os.environ.get("RT_SHARE_GPU") == "1":
+        local = 0
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d (launch with torch.distributed.run)" % (world, args.gpus))
     torch.cuda.set_device(local)

@@ -293,6 +293,7 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
   // descent early-exit threshold (Trav::round); measured C2 / C4 / C5 Grays/s:
   // 0 (off) 12.8 / 10.7 / 3.28, 8: 13.9 / - / -, 16: 13.7 / 12.0 / 4.00, 32: 13.0 / - / 4.02
   S.leafT = getenv("RT_LEAFT") ? atoi(getenv("RT_LEAFT")) : 12;
+  S.refillT = getenv("RT_REFILLT") ? atoi(getenv("RT_REFILLT")) : 24;  // measured C2: 1 -> 15.9, 8 -> 16.0, 16 -> 16.1, 32 -> 16.2 Grays/s
   S.phPos = S.phDir = nullptr;
   S.cam = sc->camera;
   if (hipMalloc(reinterpret_cast<void**>(&c->dCounters), RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||

@@ -38,6 +38,7 @@ struct DevScene {
   uint32_t n_tris, n_nodes, n_lights, n_photons;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
   uint32_t leafT;          // Trav::round leaves its descent when fewer lanes than this still descend
+  uint32_t refillT;        // vertex_pool hands out rays once this many workers are free
   rt_camera cam;
 };
 

@@ -45,8 +45,11 @@ struct HitRec {
 };
 
 RT_DEV float safe_inv(float d) {
-  // finite stand-in for 1/0 so that (lo - o) * inv never forms 0 * inf
-  return fabsf(d) < 1e-20f ? copysignf(1e20f, d) : 1.0f / d;
+  // finite stand-in for 1/0 so that lo * inv - o * inv never forms 0 * inf.  The
+  // reciprocal only feeds the (padded, conservative) slab test, never a reference
+  // expression, so the 1-ulp hardware v_rcp_f32 is enough: its error is four orders
+  // below the box padding in t units.
+  return fabsf(d) < 1e-20f ? copysignf(1e20f, d) : __builtin_amdgcn_rcpf(d);
 }
 
 RT_DEV f3 f4xyz(const float4& a) { return mk(a.x, a.y, a.z); }
@@ -499,7 +502,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, uint32_t rng0,
   T.idle();
   for (;;) {
     const uint64_t idle = __ballot(!T.live());
-    if (head < R && idle != 0) {
+    if (head < R && (__popcll(idle) >= (int)S.refillT || __popcll(idle) == 64)) {
       if (!T.live()) {
         const uint32_t r = head + lanes_below(idle);
         if (r < R) {

@@ -43,11 +43,19 @@ def barrier():
 def reduce_frame(accum, dst=0):
     """In-place SUM reduce of the per-rank accumulator onto rank `dst`."""
     if active():
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+        if accum.is_cuda and dist.get_backend() == "gloo":
+            # rehearsal mode (several ranks sharing one GPU): gloo reduces on the host
+            host = accum.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            accum.copy_(host)
+        else:
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
 
 
 def max_over_ranks(value, device):
+    if active() and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -55,6 +63,8 @@ def max_over_ranks(value, device):
 
 
 def sum_over_ranks(values, device):
+    if active() and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
     if active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

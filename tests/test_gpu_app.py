@@ -75,3 +75,26 @@ def test_reference_main_unchanged_runs_on_the_gpu(tmp_path):
     mine = np.array(got.split()[4:], float).reshape(256, 256, 3)
     mine64 = mine.reshape(64, 4, 64, 4, 3).mean((1, 3))
     assert abs(mine64.mean() - ref.mean()) / ref.mean() < 0.03
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
+    """bench.py's N-rank flow (tile sharding, reduce onto rank 0, resolve, max-over-ranks
+    timing, summed counters) rehearsed with 2 gloo ranks sharing this GPU; the ray count
+    must equal the 1-rank count (every pixel is integrated by exactly one rank)."""
+    import json
+    import sys
+    env = dict(os.environ, RT_DIST_BACKEND="gloo", RT_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29711", os.path.join(pyrt.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--workload", "C1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    r1 = subprocess.run([sys.executable, os.path.join(pyrt.ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "C1",
+                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "cpu_baseline" not in two
+    assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"] == 5526901
+    for k in ("metric", "value", "unit", "ms_per_step", "roofline", "dtype", "data", "vs_baseline", "higher_is_better"):
+        assert k in two and k in one
+    assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"]
