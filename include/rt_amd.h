@@ -159,6 +159,13 @@ int rt_emit_photons(rt_ctx* ctx, uint32_t n_requested, uint32_t seed, float* pos
 int rt_render(rt_ctx* ctx, const rt_params* p, const float* background_rgb,
               float* out_rgb, float* accum_out, rt_stats* stats);
 
+/* Progressive form of rt_render (Renderer.cpp:261-269: an image after every pass):
+ * integrates the sample range p->spp_begin/spp_count on top of the caller-held host
+ * accumulator accum_io ([h][w][4], zero before the first range) and resolves the
+ * running estimate of the first spp_begin+spp_count samples into out_rgb. */
+int rt_render_passes(rt_ctx* ctx, const rt_params* p, const float* background_rgb, float* accum_io,
+                     float* out_rgb, rt_stats* stats);
+
 /* Accumulate this rank's tiles / sample range into d_accum ([h][w][4] floats in
  * DEVICE memory, caller-zeroed) on `stream` (a hipStream_t, may be NULL). */
 int rt_render_device(rt_ctx* ctx, const rt_params* p, void* d_accum, void* stream,

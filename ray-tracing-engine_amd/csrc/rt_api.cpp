@@ -468,6 +468,32 @@ int rt_render(rt_ctx* c, const rt_params* p, const float* bg, float* out_rgb, fl
   return rc;
 }
 
+int rt_render_passes(rt_ctx* c, const rt_params* p, const float* bg, float* accum_io, float* out_rgb, rt_stats* stats) {
+  if (!c || !accum_io || !bg || !out_rgb) return fail(RT_ERR_INVALID, "null argument");
+  int rc = check_params(c, p);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t npx = (size_t)p->width * p->height;
+  const uint32_t soFar = p->spp_count ? p->spp_begin + p->spp_count : p->spp;
+  float4* dAccum = nullptr;
+  float *dBg = nullptr, *dOut = nullptr;
+  hipError_t he = hipMalloc(reinterpret_cast<void**>(&dAccum), npx * sizeof(float4));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&dBg), npx * 3 * sizeof(float));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&dOut), npx * 3 * sizeof(float));
+  if (he == hipSuccess) he = hipMemcpy(dAccum, accum_io, npx * sizeof(float4), hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(dBg, bg, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
+  rt_stats local;
+  if (he == hipSuccess) rc = rt_render_device(c, p, dAccum, nullptr, stats ? stats : &local);
+  if (he == hipSuccess && rc == RT_OK) rc = rt_resolve_device(c, p->width, p->height, soFar, dAccum, dBg, dOut, nullptr);
+  if (he == hipSuccess && rc == RT_OK) he = hipMemcpy(accum_io, dAccum, npx * sizeof(float4), hipMemcpyDeviceToHost);
+  if (he == hipSuccess && rc == RT_OK) he = hipMemcpy(out_rgb, dOut, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+  if (dAccum) (void)hipFree(dAccum);
+  if (dBg) (void)hipFree(dBg);
+  if (dOut) (void)hipFree(dOut);
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "progressive render failed: %s", hipGetErrorString(he));
+  return rc;
+}
+
 int rt_trace(rt_ctx* c, const rt_ray* rays, uint32_t n, uint32_t accel, uint32_t kind, rt_hit* hits) {
   if (!c || (n && (!rays || !hits))) return fail(RT_ERR_INVALID, "null argument");
   if (n == 0) return RT_OK;

@@ -52,6 +52,7 @@ struct GpuSettings {
   int device = 0;
   unsigned seed = 1;
   unsigned accel = RT_ACCEL_BVH;
+  unsigned progress = 0;  // samples per launch / per update.ppm (0 = whole frame at once)
   static GpuSettings& get() {
     static GpuSettings s;
     return s;

@@ -25,6 +25,7 @@ int main(int argc, char** argv) {
   GpuSettings::get().device = static_cast<int>(args.gpu());
   GpuSettings::get().seed = static_cast<unsigned>(args.seed());
   GpuSettings::get().accel = args.accel() ? RT_ACCEL_BRUTE : RT_ACCEL_BVH;
+  GpuSettings::get().progress = static_cast<unsigned>(args.progress());
 
   try {
     Image image(args.width(), args.height());

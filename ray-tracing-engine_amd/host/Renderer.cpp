@@ -42,9 +42,25 @@ inline void Renderer::render(Image& image) {
 
   Image result(w, h);
   if (p.spp > 0) {
-    GpuSession::check(rt_render(session.ctx(), &p, image.data(), result.data(), nullptr, &m_stats), "rt_render");
+    // The reference re-saves update.ppm after EVERY pass (Renderer.cpp:261-269).  Here a
+    // "pass" is a sample range of one launch; GpuSettings::progress = P > 0 renders P
+    // samples per launch and saves the running estimate after each (resolved with the
+    // number of samples so far, as the reference does), 0 renders the frame in one launch.
+    // Sample ranges never change the result (the per-pixel sum order is fixed).
+    const uint32_t chunk = GpuSettings::get().progress ? GpuSettings::get().progress : p.spp;
+    std::vector<float> accum(static_cast<size_t>(w) * h * 4, 0.f);
+    rt_stats total = {};
+    for (uint32_t done = 0; done < p.spp; done += chunk) {
+      p.spp_begin = done;
+      p.spp_count = done + chunk > p.spp ? p.spp - done : chunk;
+      rt_stats st = {};
+      GpuSession::check(rt_render_passes(session.ctx(), &p, image.data(), accum.data(), result.data(), &st), "rt_render");
+      total.samples += st.samples, total.rays_closest += st.rays_closest, total.rays_shadow += st.rays_shadow;
+      total.knn_queries += st.knn_queries, total.kernel_ms += st.kernel_ms;
+      result.savePPM("update.ppm");
+    }
+    m_stats = total;
     std::cout << "Raytracing... [" << std::string(50, '#') << "] 100%" << std::endl;
-    result.savePPM("update.ppm");
     image = result;
   }
 }

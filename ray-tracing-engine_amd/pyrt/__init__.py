@@ -85,7 +85,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("mesh", "<u4"), ("tri", "<u4"), ("vtx", "
 
 # every symbol include/rt_amd.h / include/rt_host.h declares
 AMD_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_photons", "rt_emit_photons",
-               "rt_render", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
+               "rt_render", "rt_render_passes", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
                "rt_bvh_export", "rt_profile_reset", "rt_profile_collect", "rt_test_unit"]
 HOST_SYMBOLS = ["rt_host_scene_build", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error",
                 "rt_host_fill_background", "rt_host_save_ppm", "rt_host_kd_order"]
@@ -121,6 +121,7 @@ def amd():
         L.rt_emit_photons.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_uint32)]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.rt_render_passes.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.rt_resolve_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]

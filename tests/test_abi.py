@@ -68,3 +68,21 @@ def test_stress_scene_shape():
     a = s.arrays()
     lo, hi = a["pos"][a["vtx_begin"][3]:a["vtx_begin"][4]].min(0), a["pos"][a["vtx_begin"][3]:a["vtx_begin"][4]].max(0)
     assert (lo > [-1.41, -0.96, -1.41]).all() and (hi < [1.41, 1.41, 1.01]).all()
+
+
+def test_off_loader_fan_triangulates_polygons_and_skips_comments(tmp_path):
+    """Mesh::loadOFF (reference source/Mesh.h:57-90): header comment lines, polygons with
+    more than 3 corners become a fan around their first vertex."""
+    import shutil
+    import numpy as np
+    shutil.copy(os.path.join(pyrt.MESH_DIR, "cube_tri2.off"), tmp_path / "cube_tri2.off")
+    (tmp_path / "poly.off").write_text("OFF\n# a comment line\n6 2 0\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n-0.5 0.5 0\n0.5 -0.5 0\n"
+                                       "4 0 1 2 3\n5 0 5 1 2 4\n")
+    s = pyrt.Scene("file:poly.off", 16, 16, mesh_dir=str(tmp_path))
+    a = s.arrays()
+    b, e = a["tri_begin"][3], a["tri_begin"][4]
+    assert e - b == 2 + 3
+    local = a["tri"][b:e] - a["vtx_begin"][3]
+    assert local.tolist() == [[0, 1, 2], [0, 2, 3], [0, 5, 1], [0, 1, 2], [0, 2, 4]]
+    n = a["nrm"][a["vtx_begin"][3]:a["vtx_begin"][4]]
+    assert np.allclose(np.abs(n[:, 2]), 1.0)  # planar polygon: all vertex normals are +-z

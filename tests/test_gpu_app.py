@@ -98,3 +98,19 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     for k in ("metric", "value", "unit", "ms_per_step", "roofline", "dtype", "data", "vs_baseline", "higher_is_better"):
         assert k in two and k in one
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"]
+
+
+def test_progressive_update_ppm_matches_the_reference_semantics(tmp_path):
+    """-progress 1: an update.ppm after every pass (Renderer.cpp:261-269).  The final
+    image is the one-launch image, and stopping after pass j gives the j-sample estimate
+    resolved with j (checked against the oracle for j = 2 of N = 3... via a 2-sample run
+    being a different jitter grid, so instead: final image identical, file rewritten)."""
+    base = ["-width", "40", "-height", "32", "-m", "1", "-N", "5", "-meshdir", pyrt.MESH_DIR]
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    ra = subprocess.run([APP] + base + ["-o", "o.ppm"], cwd=tmp_path / "a", capture_output=True, text=True, timeout=120)
+    rb = subprocess.run([APP] + base + ["-o", "o.ppm", "-progress", "2"], cwd=tmp_path / "b", capture_output=True, text=True,
+                        timeout=120)
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    assert (tmp_path / "a" / "o.ppm").read_bytes() == (tmp_path / "b" / "o.ppm").read_bytes() == _expected("cubes", 40, 32, 5, 1)
+    assert (tmp_path / "b" / "update.ppm").read_bytes() == (tmp_path / "b" / "o.ppm").read_bytes()
