@@ -163,6 +163,26 @@ RT_DEV f3 bsdf_eval(const rt_material& m, f3 normal, f3 wi_in, f3 wo_in) {
 // Ray.cpp:9-24 on a flattened record (p0, e1 = p1-p0, e2 = p2-p0 precomputed with
 // the same float subtraction the reference performs per test).
 RT_DEV bool tri_test(f3 o, f3 d, f3 p0, f3 e1, f3 e2, float& u, float& v, float& t) {
+  // Branch-free form: the reference returns early when |det| < EPSILON or u is out of
+  // range; here everything is evaluated (a zero det just yields inf/NaN values that
+  // the combined predicate discards) so that a wave never splits inside the test.
+  // The RESULT (bool and, when true, u v t) is the reference's bit for bit.
+  f3 pvec = cross3(d, e2);
+  float det = dot3(e1, pvec);
+  float inv = 1.0f / det;
+  f3 tvec = o - p0;
+  u = dot3(tvec, pvec) * inv;
+  f3 qvec = cross3(tvec, e1);
+  v = dot3(d, qvec) * inv;
+  t = dot3(e2, qvec) * inv;
+  const bool detOk = !(fabsf(det) < 0.000001f);
+  const bool uOk = !(u < 0.f || u > 1.f);
+  return detOk && uOk && v >= 0.f && u + v <= 1.f;
+}
+
+// Same test with the reference's early exits (leaves u, v, t untouched exactly where
+// Ray.cpp:9-24 does) — the unit-test hook compares those side effects too.
+RT_DEV bool tri_test_ref_order(f3 o, f3 d, f3 p0, f3 e1, f3 e2, float& u, float& v, float& t) {
   f3 pvec = cross3(d, e2);
   float det = dot3(e1, pvec);
   if (fabsf(det) < 0.000001f) return false;

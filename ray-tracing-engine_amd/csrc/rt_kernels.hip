@@ -122,18 +122,20 @@ struct Trav {
       float t0, t1;
       const bool h0 = slab(h2f_lo(a.x), h2f_hi(a.x), h2f_lo(a.y), h2f_hi(a.y), h2f_lo(a.z), h2f_hi(a.z), inv, oi, best, t0);
       const bool h1 = slab(h2f_lo(a.w), h2f_hi(a.w), h2f_lo(b.x), h2f_hi(b.x), h2f_lo(b.y), h2f_hi(b.y), inv, oi, best, t1);
-      if (h0 && h1) {
-        const bool swap = t1 < t0;
-        stack[sp * BLOCK] = (uint32_t)(swap ? ch.x : ch.y);
-        sp++;
-        cur = swap ? ch.y : ch.x;
-      } else if (h0 || h1) {
-        cur = h0 ? ch.x : ch.y;
-      } else if (sp > 0) {
-        sp--;
-        cur = (int32_t)stack[sp * BLOCK];
-      } else {
+      // select-based step: one divergent branch (the pop) instead of a four-way chain;
+      // the far child is stored unconditionally (the slot is simply not claimed unless
+      // both children were hit)
+      const bool both = h0 && h1, any = h0 || h1;
+      const bool takeY = both ? (t1 < t0) : h1;  // which child to enter
+      stack[sp * BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
+      sp += both ? 1 : 0;
+      cur = takeY ? ch.y : ch.x;
+      if (!any) {
         cur = TERM;
+        if (sp > 0) {
+          sp--;
+          cur = (int32_t)stack[sp * BLOCK];
+        }
       }
       // leave the descent early once only a few lanes are still descending: they
       // sit out one leaf phase (masked) instead of making everyone else wait for them
@@ -854,7 +856,7 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
       float* o = (float*)out + 4 * (size_t)i;
       const f3 p0 = ld(a), p1 = ld(a + 3), p2 = ld(a + 6);
       float u = o[1], v = o[2], t = o[3];  // outputs may stay unwritten (Ray.cpp:14)
-      const bool hit = tri_test(ld(a + 9), ld(a + 12), p0, p1 - p0, p2 - p0, u, v, t);
+      const bool hit = tri_test_ref_order(ld(a + 9), ld(a + 12), p0, p1 - p0, p2 - p0, u, v, t);
       o[0] = hit ? 1.f : 0.f, o[1] = u, o[2] = v, o[3] = t;
       break;
     }
