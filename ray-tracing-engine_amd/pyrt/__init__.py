@@ -316,3 +316,30 @@ def unit(which, inp, out_init=None, device=0):
     out = np.zeros((len(a), ow), ot) if out_init is None else np.ascontiguousarray(out_init, ot).reshape(len(a), ow).copy()
     _check(amd().rt_test_unit(device, which, _ptr(a), _ptr(out), len(a)))
     return out
+
+
+class ArrayScene:
+    """A scene assembled from numpy arrays (tests: scaled / synthetic geometry)."""
+
+    def __init__(self, pos, nrm, tri, tri_begin, vtx_begin, materials, lights, camera):
+        self._keep = [np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(nrm, np.float32),
+                      np.ascontiguousarray(tri, np.uint32), np.ascontiguousarray(tri_begin, np.uint32),
+                      np.ascontiguousarray(vtx_begin, np.uint32), np.ascontiguousarray(materials, np.float32),
+                      np.ascontiguousarray(lights, np.float32), np.ascontiguousarray(camera, np.float32)]
+        k = self._keep
+        d = SceneDesc()
+        d.n_meshes, d.n_vertices, d.n_triangles, d.n_lights = len(k[3]) - 1, len(k[0]), len(k[2]), len(k[6])
+        d.vertex_pos = k[0].ctypes.data_as(C.POINTER(C.c_float))
+        d.vertex_nrm = k[1].ctypes.data_as(C.POINTER(C.c_float))
+        d.tri_vtx = k[2].ctypes.data_as(C.POINTER(C.c_uint32))
+        d.mesh_tri_begin = k[3].ctypes.data_as(C.POINTER(C.c_uint32))
+        d.mesh_vtx_begin = k[4].ctypes.data_as(C.POINTER(C.c_uint32))
+        d.materials = k[5].ctypes.data_as(C.POINTER(Material))
+        d.lights = k[6].ctypes.data_as(C.POINTER(Light))
+        C.memmove(C.byref(d.camera), k[7].ctypes.data, 48)
+        self.desc = d
+        self.desc_ptr = C.pointer(d)
+
+    def arrays(self):
+        k = self._keep
+        return dict(pos=k[0], nrm=k[1], tri=k[2], tri_begin=k[3], vtx_begin=k[4], materials=k[5], lights=k[6], camera=k[7])

@@ -442,3 +442,53 @@ def test_frame_independent_of_samples_per_wave():
                 assert np.array_equal(bits(a), bits(base[key]))
             base[key] = a
     ctx.close()
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 37.0, 1e4])
+def test_bvh_exact_on_scaled_scenes(scale, lowres):
+    """The packed (binary16) boxes are stored as coordinate x a power of two chosen
+    from the scene extent; BVH hits must stay identical to the exhaustive loop for
+    scenes three orders of magnitude smaller / four larger than the Cornell box."""
+    s, _ = lowres
+    a = s.arrays()
+    cam = a["camera"] * np.float32(scale)
+    scaled = pyrt.ArrayScene(a["pos"] * np.float32(scale), a["nrm"], a["tri"], a["tri_begin"], a["vtx_begin"],
+                             a["materials"], a["lights"], cam)
+    ctx = pyrt.Context(scaled)
+    rays = _ray_batch(scaled, 60000, 77)
+    rays["origin"][len(rays) // 2 + len(rays) // 16:] = cam[0]
+    b = ctx.trace(rays, pyrt.ACCEL_BVH)
+    e = ctx.trace(rays, pyrt.ACCEL_BRUTE)
+    assert np.array_equal(b.view(np.uint8), e.view(np.uint8))
+    ref = orc.trace(scaled, rays[:3000])
+    assert np.array_equal(b[:3000].view(np.uint8), ref.view(np.uint8))
+    assert 0.2 < e["hit"].mean()
+    ctx.close()
+
+
+def test_degenerate_inputs_are_rejected_or_harmless():
+    s = pyrt.Scene("cubes", 16, 16)
+    a = s.arrays()
+    bad = a["pos"].copy()
+    bad[3, 1] = np.nan
+    with pytest.raises(pyrt.RtError) as e:
+        pyrt.Context(pyrt.ArrayScene(bad, a["nrm"], a["tri"], a["tri_begin"], a["vtx_begin"], a["materials"], a["lights"],
+                                     a["camera"]))
+    assert e.value.code == 1 and "non-finite" in str(e.value)
+    tri = a["tri"].copy()
+    tri[0, 0] = 9999
+    with pytest.raises(pyrt.RtError):
+        pyrt.Context(pyrt.ArrayScene(a["pos"], a["nrm"], tri, a["tri_begin"], a["vtx_begin"], a["materials"], a["lights"],
+                                     a["camera"]))
+    # a single-triangle scene and zero-area triangles still trace exactly
+    one = pyrt.ArrayScene(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [2, 2, 2], [2, 2, 2], [2, 2, 2]], np.float32),
+                          np.tile(np.array([0, 0, 1], np.float32), (6, 1)), np.array([[0, 1, 2], [3, 4, 5]], np.uint32),
+                          [0, 2], [0, 6], a["materials"][:1], a["lights"], a["camera"])
+    ctx = pyrt.Context(one)
+    rays = np.zeros(3, pyrt.RAY_DTYPE)
+    rays["origin"] = [[0.2, 0.2, 1], [0.2, 0.2, 1], [2, 2, 3]]
+    rays["direction"] = [[0, 0, -1], [0, 0, 1], [0, 0, -1]]
+    h = ctx.trace(rays)
+    assert h["hit"].tolist() == [1, 0, 0] and h["d"][0] == 1.0
+    assert np.array_equal(h.view(np.uint8), ctx.trace(rays, pyrt.ACCEL_BRUTE).view(np.uint8))
+    ctx.close()
