@@ -448,39 +448,14 @@ RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h
 // the worker overwrites with the bounce hit record (5).  Shadow results are one
 // bit per (light, lane).  Arithmetic and draw order per pixel are exactly those of
 // the sequential code, so results are bit-identical.
-constexpr int VP_PT = 0, VP_RNG = 192, VP_BNC = 256, VP_LIST = 576, VP_RES = 640, VP_LT = 648;
-constexpr int VP_WORDS = VP_LT + 10 * POOL_L + 2;
-
-// LightSource::randAreaPosition (LightSource.h:46-49) minus the vertex, for light l
-// of the table {position, vertical, horizontal, side}, replaying the stream from the
-// state it had before the first light draw of this vertex.
-RT_DEV f3 light_dir_replay(const float* LT, uint32_t l, uint32_t state, f3 pt) {
-  Rng q{state};
-  for (uint32_t x = 0; x < l; x++) q.next(), q.next();
-  const float* t = LT + 10 * l;
-  const float side = t[9];
-  const float rh = q.uniformF(-side, side);
-  const float rv = q.uniformF(-side, side);
-  return mk(t[0], t[1], t[2]) + (rv * mk(t[3], t[4], t[5])) + (rh * mk(t[6], t[7], t[8])) - pt;
-}
-
-RT_DEV void vertex_pool_init(const DevScene& S, uint32_t* pool) {
-  const uint32_t lane = threadIdx.x;
-  float* LT = reinterpret_cast<float*>(pool + VP_LT);
-  if (lane < S.n_lights && lane < (uint32_t)POOL_L) {
-    const rt_light L = S.lights[lane];
-    for (int c = 0; c < 3; c++) LT[10 * lane + c] = L.position[c], LT[10 * lane + 3 + c] = L.vertical[c], LT[10 * lane + 6 + c] = L.horizontal[c];
-    LT[10 * lane + 9] = L.side;
-  }
-  __syncthreads();
-}
+constexpr int VP_PT = 0, VP_DIR = 192, VP_BNC = VP_DIR + 192 * POOL_L, VP_LIST = VP_BNC + 320, VP_RES = VP_LIST + 64;
+constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
 
 template <bool STATS>
-RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, uint32_t rng0, f3 rayDir, uint32_t mesh, f3 hitNormal,
-                      f3 point, f3 bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
+RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
+                      f3 point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
   const uint32_t lane = threadIdx.x, nl = S.n_lights;
   float* fp = reinterpret_cast<float*>(pool);
-  const float* LT = fp + VP_LT;
   uint32_t* list = pool + VP_LIST;
   uint32_t* res = pool + VP_RES;
   const uint64_t amask = __ballot(alive);
@@ -490,8 +465,16 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, uint32_t rng0,
   if (n == 0) return color;
   if (alive) {
     fp[VP_PT + lane] = point.x, fp[VP_PT + 64 + lane] = point.y, fp[VP_PT + 128 + lane] = point.z;
-    pool[VP_RNG + lane] = rng0;
-    if (bounce) fp[VP_BNC + lane] = bdir.x, fp[VP_BNC + 64 + lane] = bdir.y, fp[VP_BNC + 128 + lane] = bdir.z;
+    // draw order of the reference: the light samples in light order (Renderer.cpp:52),
+    // then the hemisphere sample (Renderer.cpp:164)
+    for (uint32_t l = 0; l < nl; l++) {
+      const f3 tl = light_sample(g, S.lights[l]) - point;
+      fp[VP_DIR + (3 * l + 0) * 64 + lane] = tl.x, fp[VP_DIR + (3 * l + 1) * 64 + lane] = tl.y, fp[VP_DIR + (3 * l + 2) * 64 + lane] = tl.z;
+    }
+    if (bounce) {
+      bdir = hemisphere_sample(g, hitNormal);
+      fp[VP_BNC + lane] = bdir.x, fp[VP_BNC + 64 + lane] = bdir.y, fp[VP_BNC + 128 + lane] = bdir.z;
+    }
     list[lanes_below(amask)] = lane;
     st.shadow += nl;
     if (bounce) st.closest++;
@@ -513,9 +496,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, uint32_t rng0,
           const uint32_t j = list[r - k * n];
           k = bounce ? (k == 0 ? nl : k - 1) : k;
           const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
-          f3 dj;
-          if (k < nl) dj = light_dir_replay(LT, k, pool[VP_RNG + j], pj);
-          else dj = mk(fp[VP_BNC + j], fp[VP_BNC + 64 + j], fp[VP_BNC + 128 + j]);
+          const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BNC;
+          const f3 dj = mk(fp[src + j], fp[src + 64 + j], fp[src + 128 + j]);
           T.start(pj, dj, S.invBoxScale);
           T.anyHit = k < nl;
           myK = k, myJ = j;
@@ -541,7 +523,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, uint32_t rng0,
     const rt_material mat = S.mats[mesh];
     for (uint32_t l = 0; l < nl; l++) {
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
-      const f3 toLight = light_dir_replay(LT, l, rng0, point);
+      const f3 toLight = mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
       const f3 bsdf = bsdf_eval(mat, hitNormal, toLight, -rayDir);
       const f3 radiance = light_eval(S.lights[l], point);
       color = color + radiance * bsdf;
@@ -604,7 +586,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
   extern __shared__ uint32_t lds[];
   const Lds L = carve_lds<PHOTON>(lds, A.stackLevels, A.k);
   uint32_t* pool = lds + (A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK;
-  float* ex = reinterpret_cast<float*>(pool + (POOLED ? VP_WORDS : 0));  // [4][64] sample results
+  float* ex = reinterpret_cast<float*>(pool);  // [4][64] sample results; shares the pool's words (idle at that point)
   const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   LaneStats st;
@@ -622,7 +604,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
     float4 sum = owner ? accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool pooled = POOLED && (A.flags & 1u) && S.n_lights <= (uint32_t)POOL_L;
     const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
-    if (pooled) vertex_pool_init(S, pool);
     for (uint32_t base = A.s0; base < A.s1; base += S_) {
       const uint32_t i = base + sj;
       const bool active = inImage && i < A.s1;
@@ -643,17 +624,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
           if (__ballot(alive) == 0) break;
           const bool bounce = A.mode == RT_MODE_PATH && depth + 1 < nvert;  // wave-uniform
           f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, bdir = nrm;
-          const uint32_t rng0 = g.s;
-          if (alive) {
-            vertex_setup(S, h, nrm, pt);
-            for (uint32_t l = 0; l < 2 * S.n_lights; l++) g.next();  // the light draws (replayed in the pool)
-            // Renderer.cpp:164: drawn after every shaded vertex; after the LAST one the
-            // reference draws it too but never traces it, and the stream ends there
-            if (bounce) bdir = hemisphere_sample(g, nrm);
-          }
+          if (alive) vertex_setup(S, h, nrm, pt);
+          // (Renderer.cpp:164: the hemisphere sample is drawn after every shaded vertex;
+          // after the LAST one the reference draws it too but never traces it, and the
+          // stream ends there — the pool only draws it when a bounce ray follows)
           HitRec nh;
           bool nfound;
-          const f3 c = vertex_pool<STATS>(S, alive, bounce, rng0, d, h.mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
+          const f3 c = vertex_pool<STATS>(S, alive, bounce, g, d, h.mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
           if (alive) {
             if (depth == 0) c0 = c;
             else if (depth == 1) c1 = c;
@@ -918,7 +895,7 @@ template <bool BRUTE, bool PHOTON>
 static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
                                  unsigned long long* counters, hipStream_t stream) {
   const uint32_t blocks = A.n_tiles;
-  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + ((!BRUTE && !PHOTON) ? VP_WORDS : 0) + 256);
+  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + ((!BRUTE && !PHOTON) ? VP_WORDS : 256));
   if (blocks == 0) return hipSuccess;
   // MINW = 4 waves/SIMD (<= 128 VGPRs): measured +16 % over the unconstrained
   // 134-VGPR / 3-wave build on C2; the photon variant is LDS-limited to 2 anyway
