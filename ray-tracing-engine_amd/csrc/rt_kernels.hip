@@ -903,7 +903,9 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   // scene and 16 samples per wave: 4 -> 13.9, 5 -> 13.7 Grays/s; 6 and 8 lose 5-15 %
   // (the allocator spills inside the traversal loops).
   constexpr int MINW = PHOTON ? 2 : 4;
+  static const int minw = getenv("RT_MINWAVES") ? atoi(getenv("RT_MINWAVES")) : MINW;
   if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
+  else if (!BRUTE && !PHOTON && minw == 5) hipLaunchKernelGGL((k_render<false, false, false, 5>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   return hipGetLastError();
 }
