@@ -114,6 +114,7 @@ struct Trav {
 
   template <bool STATS>
   RT_DEV void round(const DevScene& S, uint32_t* stack, LaneStats& st) {
+    const int live0 = __popcll(__ballot(cur != TERM));
     while (cur >= 0) {
       const uint4* n = S.nodes + 2 * (size_t)cur;  // 32-B packed node: 12 x f16 planes + 2 refs
       const uint4 a = n[0], b = n[1];
@@ -139,7 +140,10 @@ struct Trav {
       }
       // leave the descent early once only a few lanes are still descending: they
       // sit out one leaf phase (masked) instead of making everyone else wait for them
-      if (__popcll(__ballot(cur >= 0)) < (int)S.leafT) break;
+      // (only when the lanes that would otherwise wait clearly outnumber them: in the
+      // tail of a pool, with a handful of live rays, a round must not shrink to one step)
+      const int desc = __popcll(__ballot(cur >= 0));
+      if (desc < (int)S.leafT && live0 - desc > 2 * desc) break;
     }
     if (cur < 0 && cur != TERM) {
       const uint32_t code = ~(uint32_t)cur;

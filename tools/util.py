@@ -7,7 +7,6 @@ for kind,w,spp,mode in (("lowres",512,16,1),("cubes",512,16,1),("stress",512,4,1
     p=pyrt.make_params(w,w,spp,mode=mode,seed=1,collect_stats=1)
     _,_,st=ctx.render(p,want_accum=False)
     r=st.reserved
-    rays=st.rays_closest+st.rays_shadow
-    print(kind,"node steps/ray %.2f | node-loop lane util %.3f | rounds(wave)/ray*64 %.2f | leaf-phase lane util %.3f"%(
-      st.nodes_visited/rays, st.nodes_visited/(64*r[0]), r[1]*64/rays, r[2]/(64*r[1])))
+    print(kind,"pool rounds: %d, in tail (no rays left to hand out): %.3f | avg live lanes overall %.1f, in tail %.1f, before tail %.1f"%(
+      r[0], r[1]/r[0], r[2]/r[0], r[3]/max(r[1],1), (r[2]-r[3])/max(r[0]-r[1],1)))
     ctx.close()
