@@ -217,7 +217,9 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   A.flags = noPool ? 0u : 1u;
   // stack entries: one per inner level on a root-to-leaf path; the photon k-NN
   // keeps one split distance per kd level in the same region
-  uint32_t levels = c->bvh.maxDepth + 1;
+  // a root-to-leaf path of depth d passes d inner nodes and each stacks at most one
+  // far child, so d entries suffice
+  uint32_t levels = c->bvh.maxDepth > 1 ? c->bvh.maxDepth : 1;
   if (p->use_photons) {
     uint32_t kd = 1;
     while ((1ull << kd) <= c->S.n_photons) ++kd;
@@ -293,6 +295,7 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
   // descent early-exit threshold (Trav::round); measured C2 / C4 / C5 Grays/s:
   // 0 (off) 12.8 / 10.7 / 3.28, 8: 13.9 / - / -, 16: 13.7 / 12.0 / 4.00, 32: 13.0 / - / 4.02
   S.leafT = getenv("RT_LEAFT") ? atoi(getenv("RT_LEAFT")) : 12;
+  S.stealT = getenv("RT_STEALT") ? atoi(getenv("RT_STEALT")) : 8;
   S.refillT = getenv("RT_REFILLT") ? atoi(getenv("RT_REFILLT")) : 24;  // measured C2: 1 -> 15.9, 8 -> 16.0, 16 -> 16.1, 32 -> 16.2 Grays/s
   S.phPos = S.phDir = nullptr;
   S.cam = sc->camera;

@@ -39,6 +39,7 @@ struct DevScene {
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
   uint32_t leafT;          // Trav::round leaves its descent when fewer lanes than this still descend
   uint32_t refillT;        // vertex_pool hands out rays once this many workers are free
+  uint32_t stealT;         // ... and splits the stacks of the last long rays once this many are free
   rt_camera cam;
 };
 

@@ -93,8 +93,17 @@ struct Trav {
   int sp;
   int32_t cur;
   HitRec hit;
+  // pool mode (TRAV_MIXED): several lanes may walk disjoint subtrees of ONE ray
+  // (vertex_pool: work stealing).  `stolen` = bottom stack entries handed to other
+  // lanes; closest-hit candidates are published to shared[0..1] = 64-bit key
+  // (t bits << 32 | triangle id: unsigned min == closest t, lowest id on ties —
+  // RayTracer.h:40's rule); the pixel lane recomputes u, v of the winner.
+  int stolen;
+  bool shared;  // this ray is (or was) walked by more than one lane
+  unsigned long long* sharedKey;
+  uint32_t pj;
 
-  RT_DEV void idle() { cur = TERM, found = false, sp = 0; }
+  RT_DEV void idle() { cur = TERM, found = false, sp = 0, stolen = 0, shared = false; }
   RT_DEV void start(f3 o_, f3 d_, float invScale) {
     o = o_, d = d_;
     const f3 i1 = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
@@ -102,7 +111,7 @@ struct Trav {
     // boxes are stored as coordinate * boxScale (a power of two): fold 1/boxScale in
     inv = mk(i1.x * invScale, i1.y * invScale, i1.z * invScale);
     best = 3.402823466e+38f;  // numeric_limits<float>::max(), RayTracer.h:30
-    bestId = 0, found = false, sp = 0, cur = 0;
+    bestId = 0, found = false, sp = 0, cur = 0, stolen = 0, shared = false;
     // A ray with a NaN component cannot hit anything: Ray.cpp:9-24 then yields NaN u
     // or v for every triangle and every comparison fails (hemisphere samples are NaN
     // with p ~ 3e-8).  The slab test, built from min/max that drop
@@ -184,9 +193,24 @@ struct Trav {
       if (t < best || (t == best && id < bestId)) {
         best = t, bestId = id, found = true;
         hit.t = t, hit.u = u, hit.v = v, hit.id = id, hit.mesh = __float_as_uint(q2.z);
+        if (MODE == TRAV_MIXED && shared) publish();
       }
     }
     return false;
+  }
+
+  // pool mode: make this lane's closest hit visible to the other lanes / the pixel lane
+  RT_DEV void publish() {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(hit.t) << 32) | hit.id;
+    atomicMin(sharedKey + pj, key);
+  }
+
+  // pool mode: adopt a closer hit another lane has published for the same ray
+  RT_DEV void refresh_best() {
+    const unsigned long long key = sharedKey[pj];
+    const float kt = __uint_as_float((uint32_t)(key >> 32));
+    const uint32_t kid = (uint32_t)key;
+    if (key != ~0ull && (kt < best || (kt == best && kid < bestId))) best = kt, bestId = kid;
   }
 };
 
@@ -393,6 +417,22 @@ RT_DEV void vertex_setup(const DevScene& S, const HitRec& h, f3& hitNormal, f3& 
   point = interp3(S.vpos, tv, w, h.u, h.v);
 }
 
+// The same from the triangle id alone (vertex pool: a bounce hit comes back as a
+// (t, id) key).  u, v are recomputed by Ray.cpp:9-24 on exactly the operands the
+// walker's record holds — p0 and the float edge differences bvh_build.cpp stores —
+// so they are the bits the walker had; the vertex loads are the ones the
+// interpolation needs anyway.
+RT_DEV void vertex_setup_ray(const DevScene& S, uint32_t id, f3 o, f3 d, f3& hitNormal, f3& point, uint32_t& mesh) {
+  const uint4 tv = S.triShade[id];
+  const f3 p0 = ld(S.vpos + 3 * (size_t)tv.x), p1 = ld(S.vpos + 3 * (size_t)tv.y), p2 = ld(S.vpos + 3 * (size_t)tv.z);
+  float u, v, t;
+  tri_test(o, d, p0, p1 - p0, p2 - p0, u, v, t);
+  const float w = 1.f - u - v;
+  hitNormal = unit3(interp3(S.vnrm, tv, w, u, v));
+  point = w * p0 + u * p1 + v * p2;
+  mesh = tv.w;
+}
+
 // Renderer.cpp:63-104: photon-map radiance estimate at the vertex
 template <bool STATS>
 RT_DEV f3 shade_photon(const DevScene& S, const RenderArgs& A, f3 rayDir, const HitRec& h, const Lds& L, f3 hitNormal,
@@ -447,21 +487,22 @@ RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h
 // 64 lanes work through it as WORKERS — a lane whose ray is decided fetches the next
 // undecided one (ballot + mbcnt compaction, no atomics) instead of idling until
 // the slowest of 64 rays ends.  Per pixel lane the pool holds: vertex position (3
-// words), the stream state before the light draws (1: a worker REPLAYS the two
-// draws of "its" light, so no direction is stored), bounce direction (3), which
-// the worker overwrites with the bounce hit record (5).  Shadow results are one
-// bit per (light, lane).  Arithmetic and draw order per pixel are exactly those of
+// words), one direction per light (3 x POOL_L), the bounce direction (3), the bounce
+// result as a 64-bit key (t, id).  Shadow results are one bit per (light, lane).  Arithmetic and draw order per pixel are exactly those of
 // the sequential code, so results are bit-identical.
-constexpr int VP_PT = 0, VP_DIR = 192, VP_BNC = VP_DIR + 192 * POOL_L, VP_LIST = VP_BNC + 320, VP_RES = VP_LIST + 64;
+constexpr int VP_PT = 0, VP_DIR = 192, VP_BDIR = VP_DIR + 192 * POOL_L, VP_KEY = VP_BDIR + 192, VP_LIST = VP_KEY + 128,
+              VP_RES = VP_LIST + 64;
 constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
+static_assert(VP_KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 
 template <bool STATS>
 RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
                       f3 point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
   const uint32_t lane = threadIdx.x, nl = S.n_lights;
   float* fp = reinterpret_cast<float*>(pool);
-  uint32_t* list = pool + VP_LIST;
+  uint32_t* list = pool + VP_LIST;  // rank -> pixel lane while rays are handed out; rank -> victim word while stealing
   uint32_t* res = pool + VP_RES;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(pool + VP_KEY);
   const uint64_t amask = __ballot(alive);
   const uint32_t n = (uint32_t)__popcll(amask);
   f3 color = mk(0.f, 0.f, 0.f);
@@ -477,7 +518,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
     }
     if (bounce) {
       bdir = hemisphere_sample(g, hitNormal);
-      fp[VP_BNC + lane] = bdir.x, fp[VP_BNC + 64 + lane] = bdir.y, fp[VP_BNC + 128 + lane] = bdir.z;
+      fp[VP_BDIR + lane] = bdir.x, fp[VP_BDIR + 64 + lane] = bdir.y, fp[VP_BDIR + 128 + lane] = bdir.z;
+      keys[lane] = ~0ull;
     }
     list[lanes_below(amask)] = lane;
     st.shadow += nl;
@@ -489,37 +531,87 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   uint32_t head = 0, myK = 0, myJ = 0;
   Trav<TRAV_MIXED> T;
   T.idle();
+  T.sharedKey = keys, T.pj = 0;
+  uint32_t* stackBase = stack - lane;
   for (;;) {
     const uint64_t idle = __ballot(!T.live());
-    if (head < R && (__popcll(idle) >= (int)S.refillT || __popcll(idle) == 64)) {
-      if (!T.live()) {
-        const uint32_t r = head + lanes_below(idle);
-        if (r < R) {
-          // the bounce rays (closest hit: the longest walks) are handed out first
-          uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);  // r / n for kinds <= POOL_L + 1
-          const uint32_t j = list[r - k * n];
-          k = bounce ? (k == 0 ? nl : k - 1) : k;
-          const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
-          const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BNC;
-          const f3 dj = mk(fp[src + j], fp[src + 64 + j], fp[src + 128 + j]);
-          T.start(pj, dj, S.invBoxScale);
-          T.anyHit = k < nl;
-          myK = k, myJ = j;
+    const int nIdle = __popcll(idle);
+    if (head < R) {
+      if (nIdle >= (int)S.refillT || nIdle == 64) {
+        if (!T.live()) {
+          const uint32_t r = head + lanes_below(idle);
+          if (r < R) {
+            // the bounce rays (closest hit: the longest walks) are handed out first
+            uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);  // r / n for kinds <= POOL_L + 1
+            const uint32_t j = list[r - k * n];
+            k = bounce ? (k == 0 ? nl : k - 1) : k;
+            const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
+            const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BDIR;
+            const f3 dj = mk(fp[src + j], fp[src + 64 + j], fp[src + 128 + j]);
+            T.start(pj, dj, S.invBoxScale);
+            T.anyHit = k < nl, T.pj = j;
+            myK = k, myJ = j;
+          }
         }
+        head += (uint32_t)nIdle;
       }
-      head += (uint32_t)__popcll(idle);
+    } else if (nIdle >= (int)S.stealT) {
+      // The pool is empty and many workers are free: the tail.  A few long rays would
+      // now keep 64 lanes waiting (measured: 75 % of the rounds ran with 8 live lanes).
+      // Free lanes take over the BOTTOM pending subtree of a busy lane's stack (the
+      // farthest, usually largest one) and walk it for the same ray.  The victim's slot
+      // is overwritten with TERM, which is what it must pop there anyway; any-hit rays
+      // share one result bit, closest-hit rays one atomic-min key, so the outcome is
+      // the one a single walker produces.
+      const bool canGive = T.live() && T.sp > T.stolen;
+      const uint64_t vmask = __ballot(canGive);
+      const uint32_t nv = (uint32_t)__popcll(vmask);
+      if (nv != 0) {
+        if (canGive) {
+          const uint32_t rk = lanes_below(vmask);
+          if ((int)rk < nIdle) {
+            list[rk] = lane | (myK << 8) | (myJ << 16) | ((uint32_t)T.stolen << 24);
+            T.stolen++;
+            if (!T.shared && !T.anyHit && T.found) T.publish();  // what it has found so far
+            T.shared = true;
+          }
+        }
+        __syncthreads();
+        if (!T.live()) {
+          const uint32_t q = lanes_below(idle);
+          if (q < nv) {
+            const uint32_t w = list[q];
+            const uint32_t v = w & 255u, k = (w >> 8) & 255u, j = (w >> 16) & 255u, e = w >> 24;
+            uint32_t* slot = stackBase + e * BLOCK + v;
+            const int32_t node = (int32_t)*slot;
+            *slot = (uint32_t)TERM;
+            const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
+            const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BDIR;
+            const f3 dj = mk(fp[src + j], fp[src + 64 + j], fp[src + 128 + j]);
+            T.start(pj, dj, S.invBoxScale);
+            T.cur = node;
+            T.anyHit = k < nl, T.pj = j, T.shared = true;
+            myK = k, myJ = j;
+          }
+        }
+        __syncthreads();
+      }
     }
     if (__ballot(T.live()) == 0) break;
+    if (T.shared && T.live()) {
+      // several lanes may now serve this ray: stop at a decided any-hit
+      // ray, prune with the closest hit anyone has found so far
+      if (T.anyHit) {
+        if ((res[myK * 2 + (myJ >> 5)] >> (myJ & 31)) & 1u) T.cur = TERM;
+      } else {
+        T.refresh_best();
+      }
+    }
     const bool was = T.live();
     T.template round<STATS>(S, stack, st);
-    if (was && !T.live()) {
-      if (myK < nl) {
-        if (T.found) atomicOr(&res[myK * 2 + (myJ >> 5)], 1u << (myJ & 31));
-      } else {  // bounce result replaces the bounce direction of pixel lane myJ
-        fp[VP_BNC + myJ] = T.found ? T.hit.t : -1.f;
-        fp[VP_BNC + 64 + myJ] = T.hit.u, fp[VP_BNC + 128 + myJ] = T.hit.v;
-        pool[VP_BNC + 192 + myJ] = T.hit.id, pool[VP_BNC + 256 + myJ] = T.hit.mesh;
-      }
+    if (was && !T.live() && T.found) {
+      if (myK < nl) atomicOr(&res[myK * 2 + (myJ >> 5)], 1u << (myJ & 31));
+      else if (!T.shared) T.publish();  // shared rays publish every improvement as it happens
     }
   }
   __syncthreads();
@@ -533,10 +625,10 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       color = color + radiance * bsdf;
     }
     if (bounce) {
-      const float t = fp[VP_BNC + lane];
-      nextFound = t > 0.f;
-      next.t = t, next.u = fp[VP_BNC + 64 + lane], next.v = fp[VP_BNC + 128 + lane];
-      next.id = pool[VP_BNC + 192 + lane], next.mesh = pool[VP_BNC + 256 + lane];
+      const unsigned long long key = keys[lane];
+      nextFound = key != ~0ull;
+      next.t = __uint_as_float((uint32_t)(key >> 32)), next.id = (uint32_t)key;
+      next.u = next.v = 0.f, next.mesh = 0u;  // vertex_setup_ray works from the id
     }
   }
   __syncthreads();  // the pool is rewritten by the next vertex
@@ -579,11 +671,11 @@ RT_DEV Lds carve_lds(uint32_t* base, uint32_t levels = STACK, uint32_t kslots = 
 // calculateColorPath (:106-201) with the recursion unrolled to a loop.  Control
 // flow is wave-uniform (per-lane `alive` flags instead of early exits) because the
 // direct-lighting step exchanges rays between lanes through LDS.
-template <bool BRUTE, bool PHOTON, bool STATS, int MINW>
+template <bool BRUTE, bool PHOTON, bool POOLED, bool STATS, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A, float4* __restrict__ accum,
                                                   unsigned long long* __restrict__ counters) {
   static_assert(BLOCK == 64, "the shadow-ray pool assumes one wave per workgroup");
-  constexpr bool POOLED = !BRUTE && !PHOTON;
+  static_assert(!POOLED || (!BRUTE && !PHOTON), "the vertex pool serves BVH direct lighting");
   // dynamic LDS (render_lds_bytes): [levels][64] traversal stack, sized from the
   // depth of THIS scene's trees so that LDS does not cap occupancy; then the photon
   // k-heap or the shadow-ray pool
@@ -606,7 +698,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
     const bool owner = inImage && sj == 0;  // adds this pixel's samples, in order
     const uint32_t pix = inImage ? py * A.width + px : 0u;
     float4 sum = owner ? accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool pooled = POOLED && (A.flags & 1u) && S.n_lights <= (uint32_t)POOL_L;
+    constexpr bool pooled = POOLED;  // chosen by the launcher: BVH, direct lighting, n_lights <= POOL_L
     const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
     for (uint32_t base = A.s0; base < A.s1; base += S_) {
       const uint32_t i = base + sj;
@@ -618,7 +710,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
       camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
       f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0;
       bool primary = true, alive = active;
-      if (pooled) {
+      if constexpr (pooled) {
         // primary ray (coherent: traced in lock step), then one pool per vertex
         HitRec h;
         if (alive) st.closest++;
@@ -628,18 +720,19 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
           if (__ballot(alive) == 0) break;
           const bool bounce = A.mode == RT_MODE_PATH && depth + 1 < nvert;  // wave-uniform
           f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, bdir = nrm;
-          if (alive) vertex_setup(S, h, nrm, pt);
+          uint32_t mesh = 0;
+          if (alive) vertex_setup_ray(S, h.id, o, d, nrm, pt, mesh);
           // (Renderer.cpp:164: the hemisphere sample is drawn after every shaded vertex;
           // after the LAST one the reference draws it too but never traces it, and the
           // stream ends there — the pool only draws it when a bounce ray follows)
           HitRec nh;
           bool nfound;
-          const f3 c = vertex_pool<STATS>(S, alive, bounce, g, d, h.mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
+          const f3 c = vertex_pool<STATS>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
           if (alive) {
             if (depth == 0) c0 = c;
             else if (depth == 1) c1 = c;
             else c2 = c;
-            d = bdir, h = nh;
+            o = pt, d = bdir, h = nh;
             if (!nfound) alive = false;
           }
         }
@@ -895,31 +988,31 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
 }
 
 // ---------------------------------------------------------------- launchers
-template <bool BRUTE, bool PHOTON>
+template <bool BRUTE, bool PHOTON, bool POOLED>
 static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
                                  unsigned long long* counters, hipStream_t stream) {
   const uint32_t blocks = A.n_tiles;
-  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + ((!BRUTE && !PHOTON) ? VP_WORDS : 256));
+  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + (POOLED ? VP_WORDS : 256));
   if (blocks == 0) return hipSuccess;
-  // MINW = 4 waves/SIMD (<= 128 VGPRs): measured +16 % over the unconstrained
-  // 134-VGPR / 3-wave build on C2; the photon variant is LDS-limited to 2 anyway
   // Occupancy target (waves per SIMD), measured on C2 with the LDS stack sized to the
-  // scene and 16 samples per wave: 4 -> 13.9, 5 -> 13.7 Grays/s; 6 and 8 lose 5-15 %
-  // (the allocator spills inside the traversal loops).
+  // scene: 3 -> 14.9, 4 -> 16.9, 5 -> 17.0 Grays/s (C4/C5 lose 3-5 % at 5: spills), 6 and
+  // 8 lose 5-15 %.  RT_MINWAVES=5 selects the 5-wave build of the pooled kernel.
   constexpr int MINW = PHOTON ? 2 : 4;
   static const int minw = getenv("RT_MINWAVES") ? atoi(getenv("RT_MINWAVES")) : MINW;
-  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
-  else if (!BRUTE && !PHOTON && minw == 5) hipLaunchKernelGGL((k_render<false, false, false, 5>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
-  else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
+  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
+  else if (POOLED && minw == 5) hipLaunchKernelGGL((k_render<false, false, POOLED, false, 5>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
+  else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   return hipGetLastError();
 }
 
 hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,
                          float4* accum, unsigned long long* counters, hipStream_t stream) {
-  if (brute_force) return photon ? launch_render2<true, true>(stats, S, A, accum, counters, stream)
-                                 : launch_render2<true, false>(stats, S, A, accum, counters, stream);
-  return photon ? launch_render2<false, true>(stats, S, A, accum, counters, stream)
-                : launch_render2<false, false>(stats, S, A, accum, counters, stream);
+  if (brute_force) return photon ? launch_render2<true, true, false>(stats, S, A, accum, counters, stream)
+                                 : launch_render2<true, false, false>(stats, S, A, accum, counters, stream);
+  if (photon) return launch_render2<false, true, false>(stats, S, A, accum, counters, stream);
+  // direct lighting through the BVH: the vertex pool handles up to POOL_L lights
+  if ((A.flags & 1u) && S.n_lights <= (uint32_t)POOL_L) return launch_render2<false, false, true>(stats, S, A, accum, counters, stream);
+  return launch_render2<false, false, false>(stats, S, A, accum, counters, stream);
 }
 
 hipError_t launch_resolve(uint32_t n_pixels, uint32_t spp, const float4* accum, const float* bg, float* out,
