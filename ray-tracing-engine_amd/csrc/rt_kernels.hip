@@ -491,7 +491,7 @@ RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h
 // result as a 64-bit key (t, id).  Shadow results are one bit per (light, lane).  Arithmetic and draw order per pixel are exactly those of
 // the sequential code, so results are bit-identical.
 constexpr int VP_PT = 0, VP_DIR = 192, VP_BDIR = VP_DIR + 192 * POOL_L, VP_KEY = VP_BDIR + 192, VP_LIST = VP_KEY + 128,
-              VP_RES = VP_LIST + 64;
+              VP_RES = VP_LIST + 32;
 constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
 static_assert(VP_KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 
@@ -500,7 +500,10 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
                       f3 point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
   const uint32_t lane = threadIdx.x, nl = S.n_lights;
   float* fp = reinterpret_cast<float*>(pool);
-  uint32_t* list = pool + VP_LIST;  // rank -> pixel lane while rays are handed out; rank -> victim word while stealing
+  // 32 words: rank -> pixel lane (64 bytes) while rays are handed out; then rank -> victim
+  // word while stealing (min(victims, free lanes) <= 32 entries)
+  uint32_t* list = pool + VP_LIST;
+  uint8_t* listB = reinterpret_cast<uint8_t*>(list);
   uint32_t* res = pool + VP_RES;
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(pool + VP_KEY);
   const uint64_t amask = __ballot(alive);
@@ -521,7 +524,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       fp[VP_BDIR + lane] = bdir.x, fp[VP_BDIR + 64 + lane] = bdir.y, fp[VP_BDIR + 128 + lane] = bdir.z;
       keys[lane] = ~0ull;
     }
-    list[lanes_below(amask)] = lane;
+    listB[lanes_below(amask)] = (uint8_t)lane;
     st.shadow += nl;
     if (bounce) st.closest++;
   }
@@ -543,7 +546,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
           if (r < R) {
             // the bounce rays (closest hit: the longest walks) are handed out first
             uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);  // r / n for kinds <= POOL_L + 1
-            const uint32_t j = list[r - k * n];
+            const uint32_t j = listB[r - k * n];
             k = bounce ? (k == 0 ? nl : k - 1) : k;
             const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
             const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BDIR;
@@ -994,11 +997,14 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   const uint32_t blocks = A.n_tiles;
   const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + (POOLED ? VP_WORDS : 256));
   if (blocks == 0) return hipSuccess;
-  // Occupancy target (waves per SIMD), measured on C2 with the LDS stack sized to the
-  // scene: 3 -> 14.9, 4 -> 16.9, 5 -> 17.0 Grays/s (C4/C5 lose 3-5 % at 5: spills), 6 and
-  // 8 lose 5-15 %.  RT_MINWAVES=5 selects the 5-wave build of the pooled kernel.
+  // Occupancy target (waves per SIMD).  The pooled kernel exists as a 128-VGPR (4 waves)
+  // and a 96-VGPR (5 waves, some spills) build; the fifth wave only exists if the wave's
+  // LDS (stack levels + pool) leaves room for more than 16 waves per CU.  Measured:
+  // C2 (7.8 KB) 20.0 -> 20.6 Grays/s and C4 (8.6 KB) 17.8 -> 18.4 with 5; C5 (10.1 KB,
+  // 16 waves at most) 5.43 -> 5.33, so it stays at 4.  6 and 8 lose 5-15 %.
   constexpr int MINW = PHOTON ? 2 : 4;
-  static const int minw = getenv("RT_MINWAVES") ? atoi(getenv("RT_MINWAVES")) : MINW;
+  static const int minwEnv = getenv("RT_MINWAVES") ? atoi(getenv("RT_MINWAVES")) : 0;
+  const int minw = minwEnv ? minwEnv : (POOLED && ldsBytes * 17 <= 160u * 1024u ? 5 : MINW);
   if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   else if (POOLED && minw == 5) hipLaunchKernelGGL((k_render<false, false, POOLED, false, 5>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);

@@ -23,7 +23,8 @@ out=sys.argv[1]
 agg=collections.OrderedDict()
 for f in sorted(glob.glob(out+"/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "k_render<" not in r["Kernel_Name"] or "true," in r["Kernel_Name"].split("k_render<")[1].split(">")[0].split(", ",2)[2]: continue
+        if "k_render<" not in r["Kernel_Name"]: continue
+        if r["Kernel_Name"].split("k_render<")[1].split(">")[0].split(", ")[3] == "true": continue  # the STATS build
         key=(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
         agg.setdefault(key,[]).append(float(r["Counter_Value"]))
 with open(out+"/summary.txt","w") as fo:
