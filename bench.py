@@ -178,6 +178,10 @@ def main():
                          "kernel": "k_render", "kernel_ms_avg": avg_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "nodes_per_ray": tot[2] / max(rays_per_frame, 1), "tris_per_ray": tot[3] / max(rays_per_frame, 1),
+                         # lanes doing a node step / a leaf test per wave-level step of the traversal
+                         # loop (rank 0's share; diagnostics of the counted pass)
+                         "lanes_per_node_step": st.nodes_visited / max(st.reserved[0], 1),
+                         "leaf_phases_per_node_step": st.reserved[1] / max(st.reserved[0], 1),
                          "note": "scene is %.2f MB (L2/Infinity-Cache resident): achieved is the ALGORITHMIC byte rate, "
                                  "served mostly by caches; traffic = measured HBM bytes per launch"
                                  % ((32 * ctx.bvh_info().n_nodes + 48 * scene.desc.n_triangles) / 1e6)},

@@ -195,6 +195,8 @@ int read_counters(rt_ctx* c, rt_stats* st) {
   st->nodes_visited = h[RTK_CNT_NODES];
   st->tris_tested = h[RTK_CNT_TRIS];
   st->kd_visited = h[RTK_CNT_KD];
+  st->reserved[0] = h[RTK_CNT_WNODE];  // diagnostics (collect_stats): wave-level node steps,
+  st->reserved[1] = h[RTK_CNT_WLEAF];  // wave-level leaf phases -> lane utilisation of the traversal
   return RT_OK;
 }
 

@@ -16,6 +16,8 @@ enum {
   RTK_CNT_NODES,
   RTK_CNT_TRIS,
   RTK_CNT_KD,
+  RTK_CNT_WNODE,  // wave-level node steps (a step = one descent iteration of a wave)
+  RTK_CNT_WLEAF,  // wave-level leaf phases
   RTK_CNT_COUNT = 8
 };
 

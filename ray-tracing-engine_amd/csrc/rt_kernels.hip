@@ -37,6 +37,7 @@ struct Lds {
 
 struct LaneStats {
   uint32_t closest = 0, shadow = 0, knn = 0, nodes = 0, tris = 0, kd = 0;
+  uint32_t wnode = 0, wleaf = 0;  // wave-level node steps / leaf phases (counted by the first active lane)
 };
 
 struct HitRec {
@@ -128,7 +129,7 @@ struct Trav {
       const uint4* n = S.nodes + 2 * (size_t)cur;  // 32-B packed node: 12 x f16 planes + 2 refs
       const uint4 a = n[0], b = n[1];
       const int2 ch = make_int2((int)b.z, (int)b.w);
-      if (STATS) st.nodes++;
+      if (STATS) st.nodes++, st.wnode += (uint32_t)(__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63));
       float t0, t1;
       const bool h0 = slab(h2f_lo(a.x), h2f_hi(a.x), h2f_lo(a.y), h2f_hi(a.y), h2f_lo(a.z), h2f_hi(a.z), inv, oi, best, t0);
       const bool h1 = slab(h2f_lo(a.w), h2f_hi(a.w), h2f_lo(b.x), h2f_hi(b.x), h2f_lo(b.y), h2f_hi(b.y), inv, oi, best, t1);
@@ -157,6 +158,7 @@ struct Trav {
     if (cur < 0 && cur != TERM) {
       const uint32_t code = ~(uint32_t)cur;
       const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+      if (STATS) st.wleaf += (uint32_t)(__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63));
       // leaves hold 1..leaf_max (default 2) records: the first two are tested in
       // straight-line code with both records' loads in flight together
       const float4* r = S.tris + 3 * (size_t)first;
@@ -646,7 +648,8 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool stats) {
   const uint32_t c = wave_sum(st.closest), s = wave_sum(st.shadow), q = wave_sum(st.knn);
   uint32_t n = 0, t = 0, kd = 0;
-  if (stats) n = wave_sum(st.nodes), t = wave_sum(st.tris), kd = wave_sum(st.kd);
+  uint32_t wn = 0, wl = 0;
+  if (stats) n = wave_sum(st.nodes), t = wave_sum(st.tris), kd = wave_sum(st.kd), wn = wave_sum(st.wnode), wl = wave_sum(st.wleaf);
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&counters[RTK_CNT_CLOSEST], (unsigned long long)c);
     atomicAdd(&counters[RTK_CNT_SHADOW], (unsigned long long)s);
@@ -655,6 +658,8 @@ RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool 
       atomicAdd(&counters[RTK_CNT_NODES], (unsigned long long)n);
       atomicAdd(&counters[RTK_CNT_TRIS], (unsigned long long)t);
       if (kd) atomicAdd(&counters[RTK_CNT_KD], (unsigned long long)kd);
+      atomicAdd(&counters[RTK_CNT_WNODE], (unsigned long long)wn);
+      atomicAdd(&counters[RTK_CNT_WLEAF], (unsigned long long)wl);
     }
   }
 }

@@ -18,10 +18,10 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
     rows=[]
     for f in glob.glob(out+"/"+c+"/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            # the timed (non-STATS) integrate kernel: template args <BRUTE, PHOTON, STATS=false, MINW>
+            # the timed (non-STATS) integrate kernel: template args <BRUTE, PHOTON, POOLED, STATS=false, MINW>
             if "k_render<" in r["Kernel_Name"] and r["Counter_Name"]==c:
                 targs=r["Kernel_Name"].split("k_render<")[1].split(">")[0].split(", ")
-                if targs[2]=="false": rows.append(float(r["Counter_Value"]))
+                if targs[3]=="false": rows.append(float(r["Counter_Value"]))
     vals[c]=rows
 fetch=sum(vals["FETCH_SIZE"])/max(len(vals["FETCH_SIZE"]),1)*1024
 write=sum(vals["WRITE_SIZE"])/max(len(vals["WRITE_SIZE"]),1)*1024
