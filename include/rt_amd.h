@@ -105,7 +105,9 @@ typedef struct rt_params {
   uint32_t collect_stats;     /* 1: also count BVH nodes / triangle tests      */
   uint32_t reserved[7];       /* [0]: samples of a pixel one wave integrates side by
                                  side (power of two <= 64; 0 = chosen from the grid
-                                 size).  Never changes the result, only the schedule. */
+                                 size).  [1] bit 0: shade vertices sequentially instead
+                                 of through the wave's ray pool.  Neither changes the
+                                 result, only the schedule.                       */
 } rt_params;
 
 typedef struct rt_stats {

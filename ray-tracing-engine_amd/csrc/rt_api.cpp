@@ -216,7 +216,7 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   A.mode = p->mode, A.max_depth = p->max_depth, A.seed = p->seed;
   A.k = p->k, A.photons_requested = p->photons_requested;
   static const bool noPool = getenv("RT_NO_POOL") != nullptr;
-  A.flags = noPool ? 0u : 1u;
+  A.flags = (noPool || (p->reserved[1] & 1u)) ? 0u : 1u;
   // stack entries: one per inner level on a root-to-leaf path; the photon k-NN
   // keeps one split distance per kd level in the same region
   // a root-to-leaf path of depth d passes d inner nodes and each stacks at most one

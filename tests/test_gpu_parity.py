@@ -492,3 +492,19 @@ def test_degenerate_inputs_are_rejected_or_harmless():
     assert h["hit"].tolist() == [1, 0, 0] and h["d"][0] == 1.0
     assert np.array_equal(h.view(np.uint8), ctx.trace(rays, pyrt.ACCEL_BRUTE).view(np.uint8))
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,w,h,spp", [("lowres", 1024, 1024, 4), ("hires", 512, 512, 6), ("stress", 256, 256, 3)])
+def test_pool_and_stealing_never_change_the_frame(kind, w, h, spp):
+    """Size-independent property at BASELINE-sized frames, where the oracle is too slow:
+    the vertex pool (worker lanes, tail work stealing, shared atomic-min hit keys) is a
+    SCHEDULE — the frame must equal, bit for bit, the one the sequential per-lane shading
+    of the same kernel family produces, and the ray counts must agree."""
+    s = pyrt.Scene(kind, w, h)
+    ctx = pyrt.Context(s)
+    _, a, sa = ctx.render(pyrt.make_params(w, h, spp, seed=5))
+    _, b, sb = ctx.render(pyrt.make_params(w, h, spp, seed=5, no_pool=True))
+    assert (sa.rays_closest, sa.rays_shadow, sa.samples) == (sb.rays_closest, sb.rays_shadow, sb.samples)
+    assert np.array_equal(bits(a), bits(b))
+    ctx.close()
