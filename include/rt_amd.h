@@ -186,6 +186,11 @@ int rt_knn(rt_ctx* ctx, const float* query3, uint32_t n, uint32_t k,
 /* Inspection hooks for tests (host copies of the flattened acceleration data). */
 int rt_bvh_info_get(rt_ctx* ctx, rt_bvh_info* out);
 int rt_bvh_export(rt_ctx* ctx, void* nodes64 /*n_nodes*64 B*/, void* tris48 /*n_tri_records*48 B*/);
+/* The host BVH build alone (no GPU, no context): shape, FNV-1a digest of the node and
+ * triangle arrays, and wall seconds.  threads: 0 = one per hardware thread (<= 16); the
+ * digest must not depend on it.  (No reference counterpart: BVH.h:100-161 is dead code.) */
+int rt_bvh_build_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t threads, rt_bvh_info* info,
+                      uint64_t* digest, double* seconds);
 /* Device-time bookkeeping: every rt_render_device launch is bracketed by a HIP
  * event pair on its stream.  reset() forgets them; collect() synchronises the
  * device and returns the summed kernel time of the launches since reset

@@ -1,12 +1,14 @@
-#include <cstdlib>
-// bvh_build.cpp — binned-SAH top-down build, see bvh_build.h.
+// bvh_build.cpp — binned-SAH top-down build (fork-join over the top levels), see bvh_build.h.
 #include "bvh_build.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <limits>
 #include <stdexcept>
+#include <thread>
 
 namespace rtbvh {
 namespace {
@@ -43,6 +45,7 @@ struct Builder {
   Built& out;
   uint32_t leafMax;
   int depthCap = kMaxDepth - 1;  // deepest leaf level the tree may use
+  uint32_t grain = ~0u;          // ranges above this many primitives fork a thread
 
   Builder(const rt_scene_desc& s, Built& o, uint32_t lm) : sc(s), out(o), leafMax(lm) {}
 
@@ -160,11 +163,30 @@ struct Builder {
     return m;
   }
 
-  // Builds the subtree for [b,e); returns a child reference and its (padded) box.
-  int32_t recurse(uint32_t b, uint32_t e, int depth, Box& boxOut) {
+  // One builder thread's output: nodes in pre-order with LOCAL indices.
+  struct Sub {
+    std::vector<Node> nodes;
+    uint32_t maxDepth = 0;
+  };
+
+  static void setNode(Node& nd, const Box& b0, const Box& b1, int32_t c0, int32_t c1) {
+    for (int a = 0; a < 3; ++a) {
+      nd.lo0[a] = b0.lo[a], nd.hi0[a] = b0.hi[a];
+      nd.lo1[a] = b1.lo[a], nd.hi1[a] = b1.hi[a];
+    }
+    nd.child[0] = c0, nd.child[1] = c1;
+    nd.pad[0] = nd.pad[1] = 0;
+  }
+
+  // Builds the subtree for [b,e) into `sub`; returns a child reference (local node
+  // index or leaf code) and its (padded) box.  Ranges above `grain` primitives build
+  // their right half on a new thread (fork-join): a thread only touches its own
+  // prims range and its own Sub, and the right block is appended behind the left one,
+  // so the node numbering is the sequential pre-order whatever the thread count.
+  int32_t recurse(uint32_t b, uint32_t e, int depth, Box& boxOut, Sub& sub) {
     boxOut = boundsOf(b, e);
     for (int a = 0; a < 3; ++a) boxOut.lo[a] -= out.pad, boxOut.hi[a] += out.pad;
-    out.maxDepth = std::max<uint32_t>(out.maxDepth, depth);
+    sub.maxDepth = std::max<uint32_t>(sub.maxDepth, depth);
     if (e - b <= leafMax) {
       // leaf: records in ascending global id so equal-t ties inside a leaf are
       // met lowest id first (not required for correctness, just tidy)
@@ -173,18 +195,41 @@ struct Builder {
     }
     if (depth >= kMaxDepth - 1) throw std::runtime_error("BVH depth budget exceeded");
     const uint32_t m = split(b, e, depth);
-    const int32_t self = static_cast<int32_t>(out.nodes.size());
-    out.nodes.emplace_back();
+    const int32_t self = static_cast<int32_t>(sub.nodes.size());
+    sub.nodes.emplace_back();
     Box b0, b1;
-    const int32_t c0 = recurse(b, m, depth + 1, b0);
-    const int32_t c1 = recurse(m, e, depth + 1, b1);
-    Node& nd = out.nodes[self];
-    for (int a = 0; a < 3; ++a) {
-      nd.lo0[a] = b0.lo[a], nd.hi0[a] = b0.hi[a];
-      nd.lo1[a] = b1.lo[a], nd.hi1[a] = b1.hi[a];
+    int32_t c0, c1;
+    if (e - b > grain) {
+      Sub right;
+      std::exception_ptr err;
+      std::thread t([&] {
+        try {
+          c1 = recurse(m, e, depth + 1, b1, right);
+        } catch (...) {
+          err = std::current_exception();
+        }
+      });
+      try {
+        c0 = recurse(b, m, depth + 1, b0, sub);
+      } catch (...) {
+        t.join();
+        throw;
+      }
+      t.join();
+      if (err) std::rethrow_exception(err);
+      const int32_t off = static_cast<int32_t>(sub.nodes.size());
+      for (Node nd : right.nodes) {
+        if (nd.child[0] >= 0) nd.child[0] += off;
+        if (nd.child[1] >= 0) nd.child[1] += off;
+        sub.nodes.push_back(nd);
+      }
+      if (c1 >= 0) c1 += off;
+      sub.maxDepth = std::max(sub.maxDepth, right.maxDepth);
+    } else {
+      c0 = recurse(b, m, depth + 1, b0, sub);
+      c1 = recurse(m, e, depth + 1, b1, sub);
     }
-    nd.child[0] = c0, nd.child[1] = c1;
-    nd.pad[0] = nd.pad[1] = 0;
+    setNode(sub.nodes[self], b0, b1, c0, c1);
     return self;
   }
 };
@@ -240,7 +285,7 @@ TriRec makeRec(const rt_scene_desc& sc, uint32_t t, uint32_t mesh) {
 
 }  // namespace
 
-void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out) {
+void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threads) {
   if (leafMax == 0) leafMax = 2;  // measured on C2: 2 -> 7.35, 3 -> 7.26, 4 -> 6.63, 8 -> 4.9 Grays/s
   if (leafMax > 8) leafMax = 8;
   if (sc.n_triangles == 0 || sc.n_triangles >= (1u << 28)) throw std::runtime_error("triangle count out of range");
@@ -281,27 +326,29 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out) {
   }
   out.pad = 6e-5f * std::max(1.f, maxAbs);
 
+  // threads: 0 = one per hardware thread (at most 16).  The top 6 levels fork.
+  uint32_t nthreads = threads ? threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("RT_BVH_THREADS")) nthreads = std::max(1, atoi(e));
+  B.grain = nthreads > 1 ? std::max<uint32_t>(8192u, sc.n_triangles / (4u * nthreads)) : ~0u;
+
   Box root;
+  Builder::Sub top;
   if (sc.n_triangles <= leafMax) {
     // A root node is always present (child boxes live in the parent).  The slab
     // test cannot express an "empty" box, so tiny scenes get two real leaves:
     // the two halves, or the single triangle twice (a duplicate test is a no-op
     // under the strict tie-break).
-    out.nodes.emplace_back();
+    top.nodes.emplace_back();
     const uint32_t n = sc.n_triangles, half = n >= 2 ? n / 2 : 1;
     Box b0, b1;
-    const int32_t c0 = B.recurse(0, half, 1, b0);
-    const int32_t c1 = n >= 2 ? B.recurse(half, n, 1, b1) : B.recurse(0, 1, 1, b1);
-    Node& nd = out.nodes[0];
-    for (int a = 0; a < 3; ++a) {
-      nd.lo0[a] = b0.lo[a], nd.hi0[a] = b0.hi[a];
-      nd.lo1[a] = b1.lo[a], nd.hi1[a] = b1.hi[a];
-    }
-    nd.child[0] = c0, nd.child[1] = c1;
-    nd.pad[0] = nd.pad[1] = 0;
+    const int32_t c0 = B.recurse(0, half, 1, b0, top);
+    const int32_t c1 = n >= 2 ? B.recurse(half, n, 1, b1, top) : B.recurse(0, 1, 1, b1, top);
+    Builder::setNode(top.nodes[0], b0, b1, c0, c1);
   } else {
-    B.recurse(0, sc.n_triangles, 0, root);
+    B.recurse(0, sc.n_triangles, 0, root, top);
   }
+  out.nodes.swap(top.nodes);
+  out.maxDepth = top.maxDepth;
   out.tris.resize(sc.n_triangles);
   for (uint32_t i = 0; i < sc.n_triangles; ++i) out.tris[i] = out.trisRef[B.prims[i].id];
 

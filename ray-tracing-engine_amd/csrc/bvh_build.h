@@ -68,6 +68,8 @@ struct Built {
 };
 
 // Throws std::runtime_error on an inconsistent scene description.
-void build(const rt_scene_desc& scene, uint32_t leafMax, Built& out);
+// threads: builder threads (0 = one per hardware thread, at most 16); the result does not
+// depend on it.
+void build(const rt_scene_desc& scene, uint32_t leafMax, Built& out, uint32_t threads = 0);
 
 }  // namespace rtbvh

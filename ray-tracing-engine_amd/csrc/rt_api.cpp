@@ -4,6 +4,7 @@
 // and nothing falls back to the CPU when a device is missing.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -560,6 +561,31 @@ int rt_bvh_export(rt_ctx* c, void* nodes64, void* tris48) {
   if (!c) return fail(RT_ERR_INVALID, "ctx is null");
   if (nodes64) memcpy(nodes64, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node));
   if (tris48) memcpy(tris48, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(rtbvh::TriRec));
+  return RT_OK;
+}
+
+int rt_bvh_build_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t threads, rt_bvh_info* info,
+                      uint64_t* digest, double* seconds) {
+  if (!sc || !info || !digest) return fail(RT_ERR_INVALID, "null argument");
+  try {
+    rtbvh::Built b;
+    const auto t0 = std::chrono::steady_clock::now();
+    rtbvh::build(*sc, leaf_max, b, threads);
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    info->n_nodes = (uint32_t)b.nodes.size(), info->n_tri_records = (uint32_t)b.tris.size();
+    info->max_depth = b.maxDepth, info->leaf_max = b.leafMax, info->pad = b.pad;
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over float nodes, packed nodes, triangle records
+    auto eat = [&h](const void* p, size_t n) {
+      const unsigned char* q = static_cast<const unsigned char*>(p);
+      for (size_t i = 0; i < n; ++i) h = (h ^ q[i]) * 1099511628211ull;
+    };
+    eat(b.nodes.data(), b.nodes.size() * sizeof(rtbvh::Node));
+    eat(b.nodes16.data(), b.nodes16.size() * sizeof(rtbvh::Node16));
+    eat(b.tris.data(), b.tris.size() * sizeof(rtbvh::TriRec));
+    *digest = h;
+  } catch (const std::exception& e) {
+    return fail(RT_ERR_INVALID, "BVH build failed: %s", e.what());
+  }
   return RT_OK;
 }
 

@@ -86,7 +86,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("mesh", "<u4"), ("tri", "<u4"), ("vtx", "
 # every symbol include/rt_amd.h / include/rt_host.h declares
 AMD_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_photons", "rt_emit_photons",
                "rt_render", "rt_render_passes", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
-               "rt_bvh_export", "rt_profile_reset", "rt_profile_collect", "rt_test_unit"]
+               "rt_bvh_export", "rt_bvh_build_host", "rt_profile_reset", "rt_profile_collect", "rt_test_unit"]
 HOST_SYMBOLS = ["rt_host_scene_build", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error",
                 "rt_host_fill_background", "rt_host_save_ppm", "rt_host_kd_order"]
 
@@ -130,6 +130,8 @@ def amd():
         L.rt_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_bvh_info_get.argtypes = [C.c_void_p, C.POINTER(BvhInfo)]
         L.rt_bvh_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_bvh_build_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.POINTER(BvhInfo),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.rt_profile_reset.argtypes = [C.c_void_p]
         L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.rt_test_unit.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -205,6 +207,13 @@ def background(width, height):
     bg = np.empty((height, width, 3), np.float32)
     host().rt_host_fill_background(_ptr(bg), width, height)
     return bg
+
+
+def bvh_build_host(scene, leaf_max=0, threads=0):
+    """The host BVH build alone (no GPU): (BvhInfo, digest, seconds)."""
+    info, dig, sec = BvhInfo(), C.c_uint64(0), C.c_double(0)
+    _check(amd().rt_bvh_build_host(C.byref(scene.desc), leaf_max, threads, C.byref(info), C.byref(dig), C.byref(sec)))
+    return info, dig.value, sec.value
 
 
 def kd_order(pos, dir_, weight=None):

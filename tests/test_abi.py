@@ -86,3 +86,18 @@ def test_off_loader_fan_triangulates_polygons_and_skips_comments(tmp_path):
     assert local.tolist() == [[0, 1, 2], [0, 2, 3], [0, 5, 1], [0, 1, 2], [0, 2, 4]]
     n = a["nrm"][a["vtx_begin"][3]:a["vtx_begin"][4]]
     assert np.allclose(np.abs(n[:, 2]), 1.0)  # planar polygon: all vertex normals are +-z
+
+
+def test_host_bvh_build_does_not_depend_on_thread_count():
+    """The fork-join SAH build (bvh_build.cpp) must produce the same arrays — float
+    nodes, packed f16 nodes, triangle records — for every thread count."""
+    for kind in ("cubes", "lowres", "hires"):
+        s = pyrt.Scene(kind, 32, 32)
+        runs = [pyrt.bvh_build_host(s, 0, t) for t in (1, 2, 5, 0)]
+        assert len({d for _, d, _ in runs}) == 1, kind
+        info = runs[0][0]
+        assert info.n_tri_records == s.desc.n_triangles and info.max_depth <= 31 and info.leaf_max == 2
+    # a range large enough to fork several levels deep
+    s = pyrt.Scene("stress", 32, 32)
+    a, b = pyrt.bvh_build_host(s, 0, 1), pyrt.bvh_build_host(s, 0, 8)
+    assert a[1] == b[1] and a[0].n_nodes == b[0].n_nodes and a[0].max_depth == b[0].max_depth == 22
