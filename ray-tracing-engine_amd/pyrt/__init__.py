@@ -185,7 +185,7 @@ class Scene:
         self.desc = self.desc_ptr.contents
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and host is not None:  # (module globals are gone at interpreter exit)
             host().rt_host_scene_free(self._h)
             self._h = None
 
