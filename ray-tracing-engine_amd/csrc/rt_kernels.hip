@@ -340,33 +340,57 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
   for (int j = 0; j < k; j++) H.set(j, photon_dist(S, (uint32_t)j, p, pos), (uint32_t)j);
   H.make(k);
   double bestdist = (double)H.D(0);
+  float skip2 = (float)(bestdist * bestdist * (1.0 + 1e-6));
   uint32_t visited = 0;
+  const bool mono = k >= 2;  // m_bestdist is non-increasing (see the unwind below)
   uint32_t pending = 0, wentLeft = 0;
   uint32_t b = 0, e = S.n_photons;
   int level = 0;
+  // One kdtree::knearest(node*) activation per iteration of ONE flat loop: a lane whose
+  // range ran empty unwinds to its next owed far side inside the same iteration, so all
+  // lanes of the wave arrive at the next node visit together (with a nested
+  // descend-until-empty loop, lanes that reached the bottom early waited for the
+  // deepest descent of the wave).  Invariant at the loop head: b < e.
   for (;;) {
-    while (b < e) {  // one kdtree::knearest(node*) activation per iteration
+    {
       const uint32_t n = b + (e - b) / 2;
       ++visited;
-      const float dn = photon_dist(S, n, p, pos);
-      if ((double)dn < bestdist) {
-        H.pop(k);                       // pop_heap
-        bestdist = (double)H.D(0);      // front() of the remaining k-1, then pop_back
-        H.set(k - 1, dn, n);            // push_back(*root)
-        H.push_up(k - 1, 0, dn, n);     // push_heap
+      // kdtree.h:90-92 compares the fp32 distance sqrt(d2), widened, with m_bestdist.  The
+      // correctly rounded root is only taken when d2 is not clearly out: d2 >= skip2 =
+      // m_bestdist^2 * (1 + 1e-6) rounded to float implies sqrtf(d2) >= m_bestdist (a
+      // correctly rounded sqrt is monotone and within 6e-8 relative), i.e. no insert.
+      pos = S.phPos[n];
+      const f3 dv = mk(pos.x, pos.y, pos.z) - p;
+      const float d2 = dot3(dv, dv);
+      if (!(d2 >= skip2)) {
+        const float dn = __builtin_sqrtf(d2);
+        if ((double)dn < bestdist) {
+          H.pop(k);                       // pop_heap
+          bestdist = (double)H.D(0);      // front() of the remaining k-1, then pop_back
+          H.set(k - 1, dn, n);            // push_back(*root)
+          H.push_up(k - 1, 0, dn, n);     // push_heap
+          skip2 = (float)(bestdist * bestdist * (1.0 + 1e-6));
+        }
       }
-      if (bestdist == 0) break;
-      const int axis = level % 3;
-      const float pc = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
-      const float nc = axis == 0 ? pos.x : axis == 1 ? pos.y : pos.z;
-      const float dx = nc - pc;
-      dxStack[level * BLOCK] = dx;
-      const bool left = dx > 0.f;
-      pending |= 1u << level;
-      wentLeft = left ? (wentLeft | (1u << level)) : (wentLeft & ~(1u << level));
-      if (left) e = n;
-      else b = n + 1;
-      level++;
+      if (bestdist != 0) {
+        const int axis = level % 3;
+        const float pc = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
+        const float nc = axis == 0 ? pos.x : axis == 1 ? pos.y : pos.z;
+        const float dx = nc - pc;
+        const bool left = dx > 0.f;
+        // m_bestdist never increases (k >= 2), so a far side that both prunes below
+        // already reject now stays rejected: it is not even recorded
+        const double dxd = (double)dx;
+        if (!mono || (!(dxd * dxd >= bestdist) && !((dxd < 0 ? -dxd : dxd) * (1.0 - 4.8e-7) >= bestdist))) {
+          dxStack[level * BLOCK] = dx;
+          pending |= 1u << level;
+        }
+        wentLeft = left ? (wentLeft | (1u << level)) : (wentLeft & ~(1u << level));
+        if (left) e = n;
+        else b = n + 1;
+        level++;
+        if (b < e) continue;  // descend
+      }
     }
     // unwind to the deepest activation that still owes its far-side check
     bool resumed = false;
@@ -380,10 +404,13 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
       // float subtraction; three roundings under the sqrt, one on it), and
       // m_bestdist never increases: if |dx| already exceeds it, no node of that
       // subtree can pass `d < m_bestdist` (kdtree.h:92) and the heap — hence the
-      // result — is the same whether or not the subtree is walked.  The reference's
+      // result — is the same whether or not the subtree is walked.  (Monotone for
+      // k >= 2: the new value is the second largest of the old heap plus the new point.
+      // With k = 1 "the remaining k-1" is empty and front() is the PREVIOUS insert, which
+      // may be larger than the one before it: there only the reference's own test runs.)  The reference's
       // own test is much weaker whenever m_bestdist < 1 (it needs |dx| >= sqrt of it):
       // 546 -> ~1/6 of the node visits on the C3 workload.
-      if ((dx < 0 ? -dx : dx) * (1.0 - 4.8e-7) >= bestdist) continue;
+      if (mono && (dx < 0 ? -dx : dx) * (1.0 - 4.8e-7) >= bestdist) continue;
       // rebuild the range of the level-L node from the path bits, take its far child
       uint32_t rb = 0, re = S.n_photons;
       for (int l = 0; l < L; l++) {
@@ -395,6 +422,7 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
       if (wentLeft & (1u << L)) b = m + 1, e = re, wentLeft &= ~(1u << L);
       else b = rb, e = m, wentLeft |= (1u << L);
       level = L + 1;
+      if (b >= e) continue;  // that side is empty: the activation returns at once (kdtree.h:88)
       resumed = true;
       break;
     }
