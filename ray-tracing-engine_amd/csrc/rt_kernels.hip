@@ -343,7 +343,7 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
   float skip2 = (float)(bestdist * bestdist * (1.0 + 1e-6));
   uint32_t visited = 0;
   const bool mono = k >= 2;  // m_bestdist is non-increasing (see the unwind below)
-  uint32_t pending = 0, wentLeft = 0;
+  uint32_t pending = 0, wentLeft = 0, odd = 0;
   uint32_t b = 0, e = S.n_photons;
   int level = 0;
   // One kdtree::knearest(node*) activation per iteration of ONE flat loop: a lane whose
@@ -386,6 +386,7 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
           pending |= 1u << level;
         }
         wentLeft = left ? (wentLeft | (1u << level)) : (wentLeft & ~(1u << level));
+        odd = ((e - b) & 1u) ? (odd | (1u << level)) : (odd & ~(1u << level));
         if (left) e = n;
         else b = n + 1;
         level++;
@@ -411,16 +412,19 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* 
       // own test is much weaker whenever m_bestdist < 1 (it needs |dx| >= sqrt of it):
       // 546 -> ~1/6 of the node visits on the C3 workload.
       if (mono && (dx < 0 ? -dx : dx) * (1.0 - 4.8e-7) >= bestdist) continue;
-      // rebuild the range of the level-L node from the path bits, take its far child
-      uint32_t rb = 0, re = S.n_photons;
-      for (int l = 0; l < L; l++) {
-        const uint32_t m = rb + (re - rb) / 2;
-        if (wentLeft & (1u << l)) re = m;
-        else rb = m + 1;
+      // Walk the range back UP from the current level to level L (amortised O(1) per
+      // visit; rebuilding it from the root cost O(L) per resume).  A range of s nodes
+      // splits at n = b + s/2 into a left child of s/2 and a right child of s - s/2 - 1
+      // nodes, so a child range, the side taken and the parity of s give the parent:
+      for (int l = level - 1; l >= L; l--) {
+        const uint32_t o = (odd >> l) & 1u;
+        if (wentLeft & (1u << l)) e = b + 2u * (e - b) + o;       // left child [b, n)
+        else b = e - (2u * (e - b) + 2u - o);                     // right child [n+1, e)
       }
-      const uint32_t m = rb + (re - rb) / 2;
-      if (wentLeft & (1u << L)) b = m + 1, e = re, wentLeft &= ~(1u << L);
-      else b = rb, e = m, wentLeft |= (1u << L);
+      // ... and take the far child of the level-L node
+      const uint32_t m = b + (e - b) / 2;
+      if (wentLeft & (1u << L)) b = m + 1, wentLeft &= ~(1u << L);
+      else e = m, wentLeft |= (1u << L);
       level = L + 1;
       if (b >= e) continue;  // that side is empty: the activation returns at once (kdtree.h:88)
       resumed = true;
