@@ -722,7 +722,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
   extern __shared__ uint32_t lds[];
   const Lds L = carve_lds<PHOTON>(lds, A.stackLevels, A.k);
   uint32_t* pool = lds + (A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK;
-  float* ex = reinterpret_cast<float*>(pool);  // [4][64] sample results; shares the pool's words (idle at that point)
+  // [4][64] sample results: share the pool's words, or (no pool) the first four stack
+  // levels — both idle when a sample is handed over
+  float* ex = reinterpret_cast<float*>(POOLED ? pool : lds);
   const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   LaneStats st;
@@ -1032,7 +1034,8 @@ template <bool BRUTE, bool PHOTON, bool POOLED>
 static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
                                  unsigned long long* counters, hipStream_t stream) {
   const uint32_t blocks = A.n_tiles;
-  const size_t ldsBytes = 4u * ((A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK + (POOLED ? VP_WORDS : 256));
+  const uint32_t rows = A.stackLevels + (PHOTON ? 2 * A.k : 0);
+  const size_t ldsBytes = 4u * ((rows < 4u ? 4u : rows) * BLOCK + (POOLED ? VP_WORDS : 0));
   if (blocks == 0) return hipSuccess;
   // Occupancy target (waves per SIMD).  The pooled kernel exists as a 128-VGPR (4 waves)
   // and a 96-VGPR (5 waves, some spills) build; the fifth wave only exists if the wave's
