@@ -71,7 +71,7 @@ RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
   float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
   float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
   tn = tnear;
-  return tnear <= fminf(tfar * 1.0000005f, tmax);
+  return tnear <= fminf(tfar, tmax);
 }
 
 constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane holds no live ray"
@@ -125,8 +125,11 @@ struct Trav {
   template <bool STATS>
   RT_DEV void round(const DevScene& S, uint32_t* stack, LaneStats& st) {
     const int live0 = __popcll(__ballot(cur != TERM));
+    const int exitBelow = min((int)S.leafT, (live0 + 2) / 3);
     while (cur >= 0) {
-      const uint4* n = S.nodes + 2 * (size_t)cur;  // 32-B packed node: 12 x f16 planes + 2 refs
+      // 32-B packed node: 12 x f16 planes + 2 refs (32-bit byte offset from a uniform base:
+      // the load takes the base from SGPRs)
+      const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + ((uint32_t)cur << 5));
       const uint4 a = n[0], b = n[1];
       const int2 ch = make_int2((int)b.z, (int)b.w);
       if (STATS) st.nodes++, st.wnode += (uint32_t)(__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63));
@@ -137,7 +140,7 @@ struct Trav {
       // the far child is stored unconditionally (the slot is simply not claimed unless
       // both children were hit)
       const bool both = h0 && h1, any = h0 || h1;
-      const bool takeY = both ? (t1 < t0) : h1;  // which child to enter
+      const bool takeY = h1 && (!h0 || t1 < t0);  // which child to enter (lane-mask logic, no selects)
       stack[sp * BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
       sp += both ? 1 : 0;
       cur = takeY ? ch.y : ch.x;
@@ -152,8 +155,8 @@ struct Trav {
       // sit out one leaf phase (masked) instead of making everyone else wait for them
       // (only when the lanes that would otherwise wait clearly outnumber them: in the
       // tail of a pool, with a handful of live rays, a round must not shrink to one step)
-      const int desc = __popcll(__ballot(cur >= 0));
-      if (desc < (int)S.leafT && live0 - desc > 2 * desc) break;
+      // (desc < leafT and 3 * desc < live0, folded into one threshold)
+      if (__popcll(__ballot(cur >= 0)) < exitBelow) break;
     }
     if (cur < 0 && cur != TERM) {
       const uint32_t code = ~(uint32_t)cur;
