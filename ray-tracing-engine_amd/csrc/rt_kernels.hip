@@ -168,8 +168,7 @@ struct Trav {
       const uint32_t second = cnt > 1 ? 3u : 0u;  // a 1-triangle leaf re-reads its only record
       const float4 a0 = r[0], a1 = r[1], a2 = r[2];
       const float4 b0 = r[second + 0], b1 = r[second + 1], b2 = r[second + 2];
-      bool stop = test_record<STATS>(a0, a1, a2, st);
-      if (!stop && cnt > 1) stop = test_record<STATS>(b0, b1, b2, st);
+      bool stop = test_pair<STATS>(a0, a1, a2, b0, b1, b2, cnt > 1, st);
       for (uint32_t i = 2; i < cnt && !stop; i++) {
         const float4* q = S.tris + 3 * (size_t)(first + i);
         stop = test_record<STATS>(q[0], q[1], q[2], st);
@@ -183,7 +182,36 @@ struct Trav {
     }
   }
 
-  // Ray.cpp:9-24 on one 48-B record + the acceptance rule of RayTracer.h:40.
+  // The first two records of a leaf at once and without a branch: both tests run, every
+  // acceptance is a select (RayTracer.h:40's rule applied to A, then to B), so the leaf
+  // phase stays one basic block instead of a dozen exec-mask regions.  `two` = the leaf
+  // holds a second record (else B is a re-read of A and is ignored).
+  template <bool STATS>
+  RT_DEV bool test_pair(const float4& p0, const float4& p1, const float4& p2, const float4& q0, const float4& q1,
+                        const float4& q2, bool two, LaneStats& st) {
+    if (STATS) st.tris += two ? 2u : 1u;
+    float ua, va, ta, ub, vb, tb;
+    const bool ha = tri_test(o, d, mk(p0.x, p0.y, p0.z), mk(p0.w, p1.x, p1.y), mk(p1.z, p1.w, p2.x), ua, va, ta) && ta > 0.f;
+    const bool hb = tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ub, vb, tb) && tb > 0.f && two;
+    const bool isAny = MODE == TRAV_ANY || (MODE == TRAV_MIXED && anyHit);
+    const uint32_t ida = __float_as_uint(p2.y), idb = __float_as_uint(q2.y);
+    const bool ba = !isAny && ha && (ta < best || (ta == best && ida < bestId));
+    const float b1 = ba ? ta : best;
+    const uint32_t i1 = ba ? ida : bestId;
+    const bool bb = !isAny && hb && (tb < b1 || (tb == b1 && idb < i1));
+    best = bb ? tb : b1, bestId = bb ? idb : i1;
+    if (MODE == TRAV_CLOSEST) {  // (pool mode recomputes u, v from the id: vertex_setup_ray)
+      hit.u = bb ? ub : ba ? ua : hit.u, hit.v = bb ? vb : ba ? va : hit.v;
+      hit.mesh = bb ? __float_as_uint(q2.z) : ba ? __float_as_uint(p2.z) : hit.mesh;
+    }
+    hit.t = best, hit.id = bestId;
+    found = found || (isAny ? (ha || hb) : (ba || bb));
+    if (MODE == TRAV_MIXED && shared && (ba || bb)) publish();
+    return isAny && (ha || hb);
+  }
+
+  // Ray.cpp:9-24 on one 48-B record + the acceptance rule of RayTracer.h:40 (leaves with
+  // more than two records: rt_options.bvh_leaf_max > 2).
   // Returns true when the ray is decided (any-hit rays only).
   template <bool STATS>
   RT_DEV bool test_record(const float4& q0, const float4& q1, const float4& q2, LaneStats& st) {
