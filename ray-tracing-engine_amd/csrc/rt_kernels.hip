@@ -131,6 +131,9 @@ struct Trav {
       // the load takes the base from SGPRs)
       const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + ((uint32_t)cur << 5));
       const uint4 a = n[0], b = n[1];
+      // the entry a miss would pop, fetched with the node (its latency hides behind the
+      // node's; a read in the divergent pop branch made every step wait for LDS)
+      const int32_t below = (int32_t)stack[max(sp - 1, 0) * BLOCK];
       const int2 ch = make_int2((int)b.z, (int)b.w);
       if (STATS) st.nodes++, st.wnode += (uint32_t)(__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63));
       float t0, t1;
@@ -144,13 +147,7 @@ struct Trav {
       stack[sp * BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
       sp += both ? 1 : 0;
       cur = takeY ? ch.y : ch.x;
-      if (!any) {
-        cur = TERM;
-        if (sp > 0) {
-          sp--;
-          cur = (int32_t)stack[sp * BLOCK];
-        }
-      }
+      if (!any) cur = sp > 0 ? below : TERM, sp = max(sp - 1, 0);
       // leave the descent early once only a few lanes are still descending: they
       // sit out one leaf phase (masked) instead of making everyone else wait for them
       // (only when the lanes that would otherwise wait clearly outnumber them: in the
