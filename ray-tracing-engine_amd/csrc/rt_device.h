@@ -138,25 +138,43 @@ RT_DEV float g_schlick(float alpha, f3 w, f3 n) {
   float nw = dot3(n, w);
   return nw / (nw * (1 - k) + k);
 }
-RT_DEV f3 bsdf_eval(const rt_material& m, f3 normal, f3 wi_in, f3 wo_in) {
+// evaluateColorResponse split in two: what depends on (material, normal, wo) only is
+// computed once per vertex, the rest once per light.  Same operations on the same
+// operands in the same order as the one-piece form, so the same bits.
+struct BsdfBase {
+  f3 n, wo, F0, oneMinusF0, kdDiffuse;
+  float alpha, a2, gwo, nwo, oneMinusKd;
+};
+RT_DEV BsdfBase bsdf_base(const rt_material& m, f3 normal, f3 wo_in) {
+  BsdfBase B;
+  B.n = unit3(normal), B.wo = unit3(wo_in);
+  B.alpha = m.alpha, B.a2 = m.alpha * m.alpha;
+  B.F0 = ld(m.f0), B.oneMinusF0 = mk(1.f, 1.f, 1.f) - B.F0;
+  B.gwo = g_schlick(m.alpha, B.wo, B.n);
+  B.nwo = dot3(B.n, B.wo);
+  const f3 diffuse = ld(m.albedo) / 3.14159274f;  // albedo / float(M_PI)
+  B.kdDiffuse = m.kd * diffuse, B.oneMinusKd = 1 - m.kd;
+  return B;
+}
+RT_DEV f3 bsdf_apply(const BsdfBase& B, f3 wi_in) {
   const double PI = 3.14159265358979323846;
-  f3 n = unit3(normal), wi = unit3(wi_in), wo = unit3(wo_in);
-  f3 wh = unit3(wi + wo);
-  float a2 = m.alpha * m.alpha;
-  float D = (float)((double)a2 / (PI * rt_pow2(1 + (double)(a2 - 1) * rt_pow2((double)dot3(n, wh)))));
+  f3 wi = unit3(wi_in);
+  f3 wh = unit3(wi + B.wo);
+  float D = (float)((double)B.a2 / (PI * rt_pow2(1 + (double)(B.a2 - 1) * rt_pow2((double)dot3(B.n, wh)))));
   double c = (double)dot3(wi, wh);
   float f5 = (float)rt_pow5(1 - (c > 0.0 ? c : 0.0));  // fmax(0, c); NaN -> 0 like fmax
-  f3 F0 = ld(m.f0);
-  f3 F = F0 + (mk(1.f, 1.f, 1.f) - F0) * f5;
-  float G = g_schlick(m.alpha, wi, n) * g_schlick(m.alpha, wo, n);
-  float denom = (float)(4. * (double)dot3(n, wi) * (double)dot3(n, wo));
+  f3 F = B.F0 + B.oneMinusF0 * f5;
+  float G = g_schlick(B.alpha, wi, B.n) * B.gwo;
+  float denom = (float)(4. * (double)dot3(B.n, wi) * (double)B.nwo);
   f3 spec = D * F * G / denom;
-  f3 diffuse = ld(m.albedo) / 3.14159274f;  // albedo / float(M_PI)
-  f3 r = m.kd * diffuse + (1 - m.kd) * spec;
+  f3 r = B.kdDiffuse + B.oneMinusKd * spec;
   if (r.x < 0.f) r.x = 0.f;
   if (r.y < 0.f) r.y = 0.f;
   if (r.z < 0.f) r.z = 0.f;
   return r;
+}
+RT_DEV f3 bsdf_eval(const rt_material& m, f3 normal, f3 wi_in, f3 wo_in) {
+  return bsdf_apply(bsdf_base(m, normal, wo_in), wi_in);
 }
 
 // ------------------------------------------------------------------ triangle test

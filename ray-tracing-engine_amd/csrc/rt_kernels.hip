@@ -525,7 +525,7 @@ RT_DEV f3 shade_photon(const DevScene& S, const RenderArgs& A, f3 rayDir, const 
 template <bool BRUTE, bool STATS>
 RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h, uint32_t* stack, f3 hitNormal,
                            f3 point, LaneStats& st) {
-  const rt_material mat = S.mats[h.mesh];
+  const BsdfBase base = bsdf_base(S.mats[h.mesh], hitNormal, -rayDir);  // the light-independent half, once
   f3 color = mk(0.f, 0.f, 0.f);
   for (uint32_t li = 0; li < S.n_lights; li++) {
     const rt_light Lt = S.lights[li];
@@ -533,7 +533,7 @@ RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h
     HitRec tmp;
     st.shadow++;
     if (cast<BRUTE, true, STATS>(S, true, point, toLight, stack, tmp, st)) continue;
-    const f3 bsdf = bsdf_eval(mat, hitNormal, toLight, -rayDir);
+    const f3 bsdf = bsdf_apply(base, toLight);
     const f3 radiance = light_eval(Lt, point);
     color = color + radiance * bsdf;
   }
@@ -681,11 +681,11 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   }
   __syncthreads();
   if (alive) {
-    const rt_material mat = S.mats[mesh];
+    const BsdfBase base = bsdf_base(S.mats[mesh], hitNormal, -rayDir);  // the light-independent half, once
     for (uint32_t l = 0; l < nl; l++) {
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
       const f3 toLight = mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
-      const f3 bsdf = bsdf_eval(mat, hitNormal, toLight, -rayDir);
+      const f3 bsdf = bsdf_apply(base, toLight);
       const f3 radiance = light_eval(S.lights[l], point);
       color = color + radiance * bsdf;
     }
