@@ -178,6 +178,9 @@ def main():
                        "knn_queries_per_frame": tot[5]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # what HBM actually carried (PMC bytes / the same kernel time): the honest utilisation
+                         "traffic_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic and avg_ms > 0 else None,
+                         "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
                          "kernel": "k_render", "kernel_ms_avg": avg_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "nodes_per_ray": tot[2] / max(rays_per_frame, 1), "tris_per_ray": tot[3] / max(rays_per_frame, 1),
