@@ -628,36 +628,48 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       // is overwritten with TERM, which is what it must pop there anyway; any-hit rays
       // share one result bit, closest-hit rays one atomic-min key, so the outcome is
       // the one a single walker produces.
-      const bool canGive = T.live() && T.sp > T.stolen;
-      const uint64_t vmask = __ballot(canGive);
-      const uint32_t nv = (uint32_t)__popcll(vmask);
-      if (nv != 0) {
+      // One steal event hands out up to four bottom entries per busy lane (pass p takes
+      // every victim's next one), so that a single long ray with a deep stack refills the
+      // wave at once instead of doubling its walkers round by round.  list16[slot] =
+      // victim lane | entry index << 6; the thief fetches (kind, pixel lane) from the
+      // victim's registers.
+      uint16_t* list16 = reinterpret_cast<uint16_t*>(list);
+      uint32_t given = 0;
+      for (int pass = 0; pass < 4; pass++) {
+        const bool canGive = T.live() && T.sp > T.stolen;
+        const uint64_t vmask = __ballot(canGive);
+        if (vmask == 0 || given >= (uint32_t)nIdle) break;
         if (canGive) {
-          const uint32_t rk = lanes_below(vmask);
-          if ((int)rk < nIdle) {
-            list[rk] = lane | (myK << 8) | (myJ << 16) | ((uint32_t)T.stolen << 24);
+          const uint32_t slot = given + lanes_below(vmask);
+          if (slot < (uint32_t)nIdle) {
+            list16[slot] = (uint16_t)(lane | ((uint32_t)T.stolen << 6));
             T.stolen++;
             if (!T.shared && !T.anyHit && T.found) T.publish();  // what it has found so far
             T.shared = true;
           }
         }
+        given += (uint32_t)__popcll(vmask);
+      }
+      if (given != 0) {
+        given = given < (uint32_t)nIdle ? given : (uint32_t)nIdle;
         __syncthreads();
-        if (!T.live()) {
-          const uint32_t q = lanes_below(idle);
-          if (q < nv) {
-            const uint32_t w = list[q];
-            const uint32_t v = w & 255u, k = (w >> 8) & 255u, j = (w >> 16) & 255u, e = w >> 24;
-            uint32_t* slot = stackBase + e * BLOCK + v;
-            const int32_t node = (int32_t)*slot;
-            *slot = (uint32_t)TERM;
-            const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
-            const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BDIR;
-            const f3 dj = mk(fp[src + j], fp[src + 64 + j], fp[src + 128 + j]);
-            T.start(pj, dj, S.invBoxScale);
-            T.cur = node;
-            T.anyHit = k < nl, T.pj = j, T.shared = true;
-            myK = k, myJ = j;
-          }
+        const uint32_t q = lanes_below(idle);
+        const bool thief = !T.live() && q < given;
+        const uint32_t w = thief ? (uint32_t)list16[q] : lane;
+        const uint32_t v = w & 63u, e = w >> 6;
+        const uint32_t kj = (uint32_t)__shfl((int)(myK | (myJ << 8)), (int)v, 64);  // (all lanes take part)
+        if (thief) {
+          const uint32_t k = kj & 255u, j = kj >> 8;
+          uint32_t* slot = stackBase + e * BLOCK + v;
+          const int32_t node = (int32_t)*slot;
+          *slot = (uint32_t)TERM;
+          const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
+          const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BDIR;
+          const f3 dj = mk(fp[src + j], fp[src + 64 + j], fp[src + 128 + j]);
+          T.start(pj, dj, S.invBoxScale);
+          T.cur = node;
+          T.anyHit = k < nl, T.pj = j, T.shared = true;
+          myK = k, myJ = j;
         }
         __syncthreads();
       }
