@@ -188,6 +188,8 @@ def main():
                          # loop (rank 0's share; diagnostics of the counted pass)
                          "lanes_per_node_step": st.nodes_visited / max(st.reserved[0], 1),
                          "leaf_phases_per_node_step": st.reserved[1] / max(st.reserved[0], 1),
+                         "lanes_at_leaf_per_node_step": st.reserved[2] / max(st.reserved[0], 1),
+                         "lanes_without_ray_per_node_step": st.reserved[3] / max(st.reserved[0], 1),
                          "note": "scene is %.2f MB (L2/Infinity-Cache resident): achieved is the ALGORITHMIC byte rate, "
                                  "served mostly by caches; traffic = measured HBM bytes per launch"
                                  % ((32 * ctx.bvh_info().n_nodes + 48 * scene.desc.n_triangles) / 1e6)},

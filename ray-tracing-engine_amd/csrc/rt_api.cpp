@@ -198,6 +198,8 @@ int read_counters(rt_ctx* c, rt_stats* st) {
   st->kd_visited = h[RTK_CNT_KD];
   st->reserved[0] = h[RTK_CNT_WNODE];  // diagnostics (collect_stats): wave-level node steps,
   st->reserved[1] = h[RTK_CNT_WLEAF];  // wave-level leaf phases -> lane utilisation of the traversal
+  st->reserved[2] = h[RTK_CNT_LWAIT];  // lanes holding a leaf / lanes without a ray at the START of the round,
+  st->reserved[3] = h[RTK_CNT_LIDLE];  // summed over that round's node steps
   return RT_OK;
 }
 

@@ -18,7 +18,9 @@ enum {
   RTK_CNT_KD,
   RTK_CNT_WNODE,  // wave-level node steps (a step = one descent iteration of a wave)
   RTK_CNT_WLEAF,  // wave-level leaf phases
-  RTK_CNT_COUNT = 8
+  RTK_CNT_LWAIT,  // lanes holding a leaf, summed over the wave-level node steps
+  RTK_CNT_LIDLE,  // lanes without a ray, summed over the wave-level node steps
+  RTK_CNT_COUNT = 12
 };
 
 namespace rtk {

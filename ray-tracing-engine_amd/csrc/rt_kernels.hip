@@ -38,6 +38,7 @@ struct Lds {
 struct LaneStats {
   uint32_t closest = 0, shadow = 0, knn = 0, nodes = 0, tris = 0, kd = 0;
   uint32_t wnode = 0, wleaf = 0;  // wave-level node steps / leaf phases (counted by the first active lane)
+  uint32_t lwait = 0, lidle = 0;  // lanes holding a leaf / no ray during those node steps
 };
 
 struct HitRec {
@@ -126,6 +127,8 @@ struct Trav {
   RT_DEV void round(const DevScene& S, uint32_t* stack, LaneStats& st) {
     const int live0 = __popcll(__ballot(cur != TERM));
     const int exitBelow = min((int)S.leafT, (live0 + 2) / 3);
+    uint32_t statWait = 0, statIdle = 0;
+    if (STATS) statWait = (uint32_t)__popcll(__ballot(cur < 0 && cur != TERM)), statIdle = (uint32_t)__popcll(__ballot(cur == TERM));
     while (cur >= 0) {
       // 32-B packed node: 12 x f16 planes + 2 refs (32-bit byte offset from a uniform base:
       // the load takes the base from SGPRs)
@@ -135,7 +138,10 @@ struct Trav {
       // node's; a read in the divergent pop branch made every step wait for LDS)
       const int32_t below = (int32_t)stack[max(sp - 1, 0) * BLOCK];
       const int2 ch = make_int2((int)b.z, (int)b.w);
-      if (STATS) st.nodes++, st.wnode += (uint32_t)(__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63));
+      if (STATS) {
+        st.nodes++;
+        if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63)) st.wnode++, st.lwait += statWait, st.lidle += statIdle;
+      }
       float t0, t1;
       const bool h0 = slab(h2f_lo(a.x), h2f_hi(a.x), h2f_lo(a.y), h2f_hi(a.y), h2f_lo(a.z), h2f_hi(a.z), inv, oi, best, t0);
       const bool h1 = slab(h2f_lo(a.w), h2f_hi(a.w), h2f_lo(b.x), h2f_hi(b.x), h2f_lo(b.y), h2f_hi(b.y), inv, oi, best, t1);
@@ -721,7 +727,8 @@ RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool 
   const uint32_t c = wave_sum(st.closest), s = wave_sum(st.shadow), q = wave_sum(st.knn);
   uint32_t n = 0, t = 0, kd = 0;
   uint32_t wn = 0, wl = 0;
-  if (stats) n = wave_sum(st.nodes), t = wave_sum(st.tris), kd = wave_sum(st.kd), wn = wave_sum(st.wnode), wl = wave_sum(st.wleaf);
+  uint32_t lw = 0, li = 0;
+  if (stats) n = wave_sum(st.nodes), t = wave_sum(st.tris), kd = wave_sum(st.kd), wn = wave_sum(st.wnode), wl = wave_sum(st.wleaf), lw = wave_sum(st.lwait), li = wave_sum(st.lidle);
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&counters[RTK_CNT_CLOSEST], (unsigned long long)c);
     atomicAdd(&counters[RTK_CNT_SHADOW], (unsigned long long)s);
@@ -732,6 +739,8 @@ RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool 
       if (kd) atomicAdd(&counters[RTK_CNT_KD], (unsigned long long)kd);
       atomicAdd(&counters[RTK_CNT_WNODE], (unsigned long long)wn);
       atomicAdd(&counters[RTK_CNT_WLEAF], (unsigned long long)wl);
+      atomicAdd(&counters[RTK_CNT_LWAIT], (unsigned long long)lw);
+      atomicAdd(&counters[RTK_CNT_LIDLE], (unsigned long long)li);
     }
   }
 }
