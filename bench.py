@@ -53,6 +53,15 @@ def cpu_baseline(scene_kind, mode, spp_full):
     _, _, st = orc.render(scene, p, math_mode=orc.MATH_LIBM)
     t_port = time.perf_counter() - t0
     rays = st.rays_closest + st.rays_shadow
+    # the same sample on ALL host cores: the CPU restatement in pixel-RNG mode (independent
+    # pixels, OpenMP), brute force like the reference.  (The reference itself cannot run
+    # multi-threaded: one global RNG.)
+    pp = pyrt.make_params(w, h, n, mode=mode, rng_mode=pyrt.RNG_PIXEL)
+    t0 = time.perf_counter()
+    _, _, stp = orc.render(scene, pp, math_mode=orc.MATH_DET, threads=0)
+    t_all = time.perf_counter() - t0
+    all_cores = {"port_all_cores_value": (stp.rays_closest + stp.rays_shadow) / t_all / 1e6,
+                 "port_all_cores_threads": os.cpu_count()}
     sample = "%s scene, %dx%d, -m %d -N %d, legacy RNG seed 1 (%d rays)" % (scene_kind, w, h, mode, n, rays)
     if os.path.exists(harness):
         try:
@@ -61,11 +70,11 @@ def cpu_baseline(scene_kind, mode, spp_full):
                                    cwd=tmp, capture_output=True, text=True, check=True, timeout=300)
             secs = json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
             return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference", "sample": sample,
-                    "seconds": secs, "port_value": rays / t_port / 1e6}
+                    "seconds": secs, "port_value": rays / t_port / 1e6, **all_cores}
         except Exception as e:  # the baseline must never cost the bench line: fall back to the port
             sample += " [reference harness failed: %s]" % type(e).__name__
     return {"value": rays / t_port / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample,
-            "seconds": t_port}
+            "seconds": t_port, **all_cores}
 
 
 def main():
