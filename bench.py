@@ -61,7 +61,7 @@ def cpu_baseline(scene_kind, mode, spp_full):
     _, _, stp = orc.render(scene, pp, math_mode=orc.MATH_DET, threads=0)
     t_all = time.perf_counter() - t0
     all_cores = {"port_all_cores_value": (stp.rays_closest + stp.rays_shadow) / t_all / 1e6,
-                 "port_all_cores_threads": os.cpu_count()}
+                 "port_all_cores_threads": len(os.sched_getaffinity(0))}
     sample = "%s scene, %dx%d, -m %d -N %d, legacy RNG seed 1 (%d rays)" % (scene_kind, w, h, mode, n, rays)
     if os.path.exists(harness):
         try:
