@@ -52,7 +52,7 @@ struct RenderArgs {
   uint32_t n_tiles;
   uint32_t width, height, spp, s0, s1, mode, max_depth, seed, k, photons_requested;
   uint32_t flags;         // bit 0: shadow rays through the wave-level pool
-  uint32_t stackLevels;   // LDS traversal-stack entries per lane (BVH / kd depth + 1)
+  uint32_t stackLevels;   // LDS traversal-stack entries per lane (BVH depth; kd depth + 1 with photons)
   uint32_t sshift;        // a wave = (64 >> sshift) pixels x (1 << sshift) samples side by side
   uint32_t tileW, tileH;  // pixel footprint of one wave (tileW * tileH == 64 >> sshift)
 };

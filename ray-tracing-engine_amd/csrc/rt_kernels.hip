@@ -78,12 +78,13 @@ RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
 constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane holds no live ray"
 
 // One lane's ray in flight.  round() advances every lane of the wave that holds a
-// live ray by one "while-while" round: first the wave descends inner nodes until
-// EVERY live lane holds a leaf (lanes that already have one sit out, masked), then
-// all leaves are intersected together — each wave iteration runs one kind of work
-// instead of the union of both (the single-loop form measured 34 % lane utilisation
-// on incoherent rays).  Between rounds a caller may hand finished lanes new rays
-// (shadow-ray pool below).
+// live ray by one "while-while" round: first the wave descends inner nodes until only a
+// few lanes are still descending (lanes that already hold a leaf sit out, masked; the
+// stragglers sit out the leaf phase), then all held leaves are intersected together —
+// each wave iteration runs one kind of work instead of the union of both (the
+// single-loop form measured 34 % lane utilisation on incoherent rays).  Between rounds
+// a caller may hand finished lanes new rays or parts of other lanes' rays (vertex pool
+// below).
 constexpr int TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_MIXED = 2;  // MIXED: per-lane `anyHit` flag
 
 template <int MODE>
