@@ -31,8 +31,7 @@ constexpr int KMAX = RTK_KMAX;           // photon heap capacity per lane
 
 struct Lds {
   uint32_t* stack;  // [STACK][BLOCK] this thread's column: stack[level * BLOCK]
-  float* heapD;     // [KMAX][BLOCK]
-  uint32_t* heapI;  // [KMAX][BLOCK]
+  uint2* heap;      // [KMAX][BLOCK] {distance bits, photon index}
 };
 
 struct LaneStats {
@@ -308,12 +307,11 @@ RT_DEV f3 interp3(const float* arr, uint4 tv, float w, float u, float v) {
 // (bits/stl_heap.h: __push_heap / __adjust_heap) because result ORDER feeds a
 // float sum (Renderer.cpp:93-96).
 struct Heap {
-  float* d;     // [slot * BLOCK]
-  uint32_t* i;  // [slot * BLOCK]
-  RT_DEV float D(int s) const { return d[s * BLOCK]; }
-  RT_DEV uint32_t I(int s) const { return i[s * BLOCK]; }
-  RT_DEV void set(int s, float dv, uint32_t iv) const { d[s * BLOCK] = dv, i[s * BLOCK] = iv; }
-  RT_DEV void move(int dst, int src) const { d[dst * BLOCK] = d[src * BLOCK], i[dst * BLOCK] = i[src * BLOCK]; }
+  uint2* e;  // [slot * BLOCK]: {distance bits, photon index} in one 8-byte word (one LDS op per move)
+  RT_DEV float D(int s) const { return __uint_as_float(e[s * BLOCK].x); }
+  RT_DEV uint32_t I(int s) const { return e[s * BLOCK].y; }
+  RT_DEV void set(int s, float dv, uint32_t iv) const { e[s * BLOCK] = make_uint2(__float_as_uint(dv), iv); }
+  RT_DEV void move(int dst, int src) const { e[dst * BLOCK] = e[src * BLOCK]; }
 
   RT_DEV void push_up(int hole, int top, float vd, uint32_t vi) const {
     int parent = (hole - 1) / 2;
@@ -507,7 +505,7 @@ template <bool STATS>
 RT_DEV f3 shade_photon(const DevScene& S, const RenderArgs& A, f3 rayDir, const HitRec& h, const Lds& L, f3 hitNormal,
                        f3 point, LaneStats& st) {
   const rt_material mat = S.mats[h.mesh];
-  const Heap H{L.heapD, L.heapI};
+  const Heap H{L.heap};
   const int k = (int)A.k;
   st.knn++;
   const uint32_t vis = knn_query(S, point, k, H, reinterpret_cast<float*>(L.stack));
@@ -751,8 +749,7 @@ template <bool PHOTON>
 RT_DEV Lds carve_lds(uint32_t* base, uint32_t levels = STACK, uint32_t kslots = KMAX) {
   Lds L;
   L.stack = base + threadIdx.x;
-  L.heapD = PHOTON ? reinterpret_cast<float*>(base + levels * BLOCK) + threadIdx.x : nullptr;
-  L.heapI = PHOTON ? base + (levels + kslots) * BLOCK + threadIdx.x : nullptr;
+  L.heap = PHOTON ? reinterpret_cast<uint2*>(base + levels * BLOCK) + threadIdx.x : nullptr;
   return L;
 }
 
@@ -932,7 +929,7 @@ __global__ __launch_bounds__(BLOCK) void k_knn(DevScene S, const float* __restri
   const Lds L = carve_lds<true>(lds);
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  const Heap H{L.heapD, L.heapI};
+  const Heap H{L.heap};
   const uint32_t vis = knn_query(S, ld(q + 3 * (size_t)i), (int)k, H, reinterpret_cast<float*>(L.stack));
   for (uint32_t j = 0; j < k; j++) {
     idx[(size_t)i * k + j] = H.I((int)j);
