@@ -115,7 +115,7 @@ typedef struct rt_stats {
   uint64_t rays_closest;   /* closest-hit casts (primary + bounce)              */
   uint64_t rays_shadow;    /* any-hit casts                                     */
   uint64_t knn_queries;
-  uint64_t nodes_visited;  /* 64-B BVH node records fetched (collect_stats)     */
+  uint64_t nodes_visited;  /* 32-B packed BVH node records fetched (collect_stats) */
   uint64_t tris_tested;    /* 48-B triangle records tested (collect_stats)      */
   uint64_t kd_visited;     /* kd-tree nodes visited (collect_stats)             */
   double kernel_ms;        /* device time of the integrate kernel(s)            */
@@ -177,6 +177,9 @@ int rt_resolve_device(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp
                       const void* d_accum, const void* d_background_rgb,
                       void* d_out_rgb, void* stream);
 
+/* Ray origins: the BVH's exactness argument (box padding vs the float triangle test's
+ * error) covers origins up to 16 x max(|scene coordinate|, |camera|, |light position|);
+ * rays that start farther out are answered by the exhaustive loop, transparently. */
 int rt_trace(rt_ctx* ctx, const rt_ray* rays, uint32_t n, uint32_t accel,
              uint32_t kind, rt_hit* hits);
 int rt_knn(rt_ctx* ctx, const float* query3, uint32_t n, uint32_t k,
@@ -185,6 +188,8 @@ int rt_knn(rt_ctx* ctx, const float* query3, uint32_t n, uint32_t k,
 
 /* Inspection hooks for tests (host copies of the flattened acceleration data). */
 int rt_bvh_info_get(rt_ctx* ctx, rt_bvh_info* out);
+/* nodes64: the float (64-B) form of the node records — the device traverses the same
+ * nodes packed to 32 B (binary16 planes rounded outward). */
 int rt_bvh_export(rt_ctx* ctx, void* nodes64 /*n_nodes*64 B*/, void* tris48 /*n_tri_records*48 B*/);
 /* The host BVH build alone (no GPU, no context): shape, FNV-1a digest of the node and
  * triangle arrays, and wall seconds.  threads: 0 = one per hardware thread (<= 16); the
@@ -213,6 +218,9 @@ int rt_profile_collect(rt_ctx* ctx, double* total_kernel_ms, uint32_t* launches)
  *   RT_UNIT_LIGHT_EVAL   in: rt_light(21 f) point3        out: rgb
  *   RT_UNIT_SAMPLERS     in: state idx N pad normal3 rt_light(21 f)  (28 words)
  *                        out: jitter xy, hemisphere dir3, light sample3, end state, pad3 (12 words)
+ *   RT_UNIT_LIGHT_SAMPLE in: state rt_light(21 f) (22 words)  out: sample3, end state
+ *                        (LightSource.h:46-49 randAreaPosition from a given engine state)
+ *   RT_UNIT_POW          in: double x                     out: double x^2, x^5 (Material.h:38,48 pow)
  */
 enum {
   RT_UNIT_ASIN = 0,
@@ -223,7 +231,9 @@ enum {
   RT_UNIT_BSDF = 5,
   RT_UNIT_RAY_AT = 6,
   RT_UNIT_LIGHT_EVAL = 7,
-  RT_UNIT_SAMPLERS = 8
+  RT_UNIT_SAMPLERS = 8,
+  RT_UNIT_LIGHT_SAMPLE = 9,
+  RT_UNIT_POW = 10
 };
 int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint32_t n);
 

@@ -140,10 +140,152 @@ struct Hit {
   float u = 0, v = 0, d = 0;
 };
 
+// ------------------------------------------------- CPU acceleration structure
+// NOT a restatement of anything (the reference's BVH.h / AABB.cpp are dead code
+// with the bugs listed in SURVEY.md App. A.4): a plain median-split BVH over
+// double-precision padded boxes whose ONLY job is to make the restatement of
+// RayTracer.h:27-53 below cheaper on big scenes.  It must return what the exhaustive
+// loop returns, bit for bit: every candidate is tested by the same float
+// triangleIntersect, the acceptance rule is the loop's (closest positive t, lowest
+// (mesh, triangle) on ties), and a box may only be skipped when no triangle inside it
+// can be accepted — boxes are padded far beyond the float test's own error and the
+// slab test runs in double.  tests/test_oracle_bvh.py checks the equivalence.
+struct OBvh {
+  struct Node {
+    double lo[3], hi[3];
+    int32_t left, right;     // children (inner) or -1
+    uint32_t first, count;   // ids[first, first+count) (leaf)
+  };
+  std::vector<Node> nodes;
+  std::vector<uint32_t> ids;   // global triangle ids
+  std::vector<uint32_t> meshOf;
+  double pad = 0, maxAbs = 0;
+
+  static void triBox(const rt_scene_desc& sc, uint32_t t, double lo[3], double hi[3]) {
+    for (int a = 0; a < 3; a++) lo[a] = 1e300, hi[a] = -1e300;
+    for (int j = 0; j < 3; j++) {
+      const float* p = sc.vertex_pos + 3 * (size_t)sc.tri_vtx[3 * (size_t)t + j];
+      for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], (double)p[a]), hi[a] = std::max(hi[a], (double)p[a]);
+    }
+  }
+  void build(const rt_scene_desc& sc) {
+    const uint32_t n = sc.n_triangles;
+    ids.resize(n);
+    meshOf.resize(n);
+    for (uint32_t m = 0; m < sc.n_meshes; m++)
+      for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; t++) meshOf[t] = m;
+    std::vector<double> cen((size_t)n * 3);
+    for (uint32_t t = 0; t < n; t++) {
+      ids[t] = t;
+      double lo[3], hi[3];
+      triBox(sc, t, lo, hi);
+      for (int a = 0; a < 3; a++) {
+        cen[3 * (size_t)t + a] = 0.5 * (lo[a] + hi[a]);
+        maxAbs = std::max(maxAbs, std::max(fabs(lo[a]), fabs(hi[a])));
+      }
+    }
+    pad = 1e-4 * std::max(1.0, maxAbs);
+    nodes.clear();
+    nodes.reserve(n);
+    split(sc, cen, 0, n);
+  }
+  int32_t split(const rt_scene_desc& sc, const std::vector<double>& cen, uint32_t b, uint32_t e) {
+    const int32_t me = (int32_t)nodes.size();
+    nodes.push_back(Node());
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = b; i < e; i++) {
+      double l[3], h[3];
+      triBox(sc, ids[i], l, h);
+      for (int a = 0; a < 3; a++) {
+        lo[a] = std::min(lo[a], l[a]), hi[a] = std::max(hi[a], h[a]);
+        clo[a] = std::min(clo[a], cen[3 * (size_t)ids[i] + a]), chi[a] = std::max(chi[a], cen[3 * (size_t)ids[i] + a]);
+      }
+    }
+    Node nd;
+    for (int a = 0; a < 3; a++) nd.lo[a] = lo[a] - pad, nd.hi[a] = hi[a] + pad;
+    nd.left = nd.right = -1, nd.first = b, nd.count = e - b;
+    if (e - b > 4) {
+      int ax = 0;
+      for (int a = 1; a < 3; a++)
+        if (chi[a] - clo[a] > chi[ax] - clo[ax]) ax = a;
+      const uint32_t mid = b + (e - b) / 2;
+      std::nth_element(ids.begin() + b, ids.begin() + mid, ids.begin() + e, [&](uint32_t x, uint32_t y) {
+        const double cx = cen[3 * (size_t)x + ax], cy = cen[3 * (size_t)y + ax];
+        return cx < cy || (cx == cy && x < y);
+      });
+      nd.count = 0;
+      nd.left = split(sc, cen, b, mid);
+      nd.right = split(sc, cen, mid, e);
+    }
+    nodes[me] = nd;
+    return me;
+  }
+  // entry distance of the ray into the node's box inflated by `extra`, or -1: the box
+  // cannot contain an acceptable hit closer than `best`
+  static double enter(const Node& nd, const double o[3], const double d[3], double extra, double best) {
+    double tn = 0, tf = best;
+    for (int a = 0; a < 3; a++) {
+      const double lo = nd.lo[a] - extra, hi = nd.hi[a] + extra;
+      if (d[a] == 0) {
+        if (o[a] < lo || o[a] > hi) return -1;
+        continue;
+      }
+      double t0 = (lo - o[a]) / d[a], t1 = (hi - o[a]) / d[a];
+      if (t0 > t1) std::swap(t0, t1);
+      tn = std::max(tn, t0), tf = std::min(tf, t1);
+    }
+    return tn <= tf ? tn : -1;
+  }
+};
+
 // ---------------------------------------------------------- RayTracer.h:27-53
-inline Hit rayTrace(const rt_scene_desc& sc, const Ray& r, Counters* c) {
+// `bvh` (optional) only narrows the set of triangles the loop body runs on.
+inline Hit rayTrace(const rt_scene_desc& sc, const Ray& r, Counters* c, const OBvh* bvh = nullptr,
+                    bool anyHit = false, uint64_t* nodesVisited = nullptr) {
   Hit h;
   float closest = std::numeric_limits<float>::max();
+  if (bvh) {
+    const float rv[6] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z};
+    for (float f : rv)
+      if (f != f) return h;  // a NaN component fails every comparison of Ray.cpp:9-24: no hit
+    const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+    // the float test's error grows with the distance of the origin from the geometry
+    const double extra = 1e-5 * std::max(fabs(o[0]), std::max(fabs(o[1]), fabs(o[2])));
+    uint32_t bestId = 0;
+    int32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+      const OBvh::Node& nd = bvh->nodes[stack[--sp]];
+      if (nodesVisited) ++*nodesVisited;
+      // (1 + 1e-6): `closest` is a float result; keep boxes that start exactly there (ties)
+      if (OBvh::enter(nd, o, d, extra, (double)closest * (1.0 + 1e-6)) < 0) continue;
+      if (nd.left >= 0) {
+        const double tl = OBvh::enter(bvh->nodes[nd.left], o, d, extra, 1e300);
+        const double tr = OBvh::enter(bvh->nodes[nd.right], o, d, extra, 1e300);
+        if (tl >= 0 && (tr < 0 || tl <= tr)) stack[sp++] = nd.right, stack[sp++] = nd.left;  // near child on top
+        else stack[sp++] = nd.left, stack[sp++] = nd.right;
+        continue;
+      }
+      for (uint32_t i = nd.first; i < nd.first + nd.count; i++) {
+        const uint32_t t = bvh->ids[i];
+        const uint32_t* iv = sc.tri_vtx + 3 * (size_t)t;
+        float ut, vt, dt;
+        if (c) c->tri_tests++;
+        if (triangleIntersect(r, ld3(sc.vertex_pos + 3 * (size_t)iv[0]), ld3(sc.vertex_pos + 3 * (size_t)iv[1]),
+                              ld3(sc.vertex_pos + 3 * (size_t)iv[2]), ut, vt, dt)) {
+          // the loop's `dt > 0 && dt < closest` in (mesh, triangle) order == lowest id on ties
+          if (dt > 0.f && (dt < closest || (dt == closest && h.found && t < bestId))) {
+            h.found = true, closest = dt, bestId = t;
+            h.mesh = bvh->meshOf[t], h.tri = t, h.u = ut, h.v = vt, h.d = dt;
+            if (anyHit) return h;
+          }
+        }
+      }
+    }
+    return h;
+  }
   for (uint32_t m = 0; m < sc.n_meshes; m++)
     for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; t++) {
       const uint32_t* iv = sc.tri_vtx + 3 * (size_t)t;
@@ -319,6 +461,8 @@ struct Ctx {
   int k;
   int numPhotons;
   Counters cnt;
+  const OBvh* bvh = nullptr;  // optional CPU acceleration (same results, see OBvh)
+  uint64_t nodes = 0;
 };
 
 inline V3 interp(const float* arr, const uint32_t* iv, float w, float u, float v) {
@@ -364,7 +508,7 @@ inline V3 shade(Ctx& c, Engine& e, const Ray& ray, const Hit& h, V3& hitNormal,
     const rt_light& L = sc.lights[li];
     V3 toLight = randAreaPosition(e, L) - trianglePoint;
     c.cnt.shadow++;
-    if (rayTrace(sc, Ray{trianglePoint, toLight}, &c.cnt).found) continue;
+    if (rayTrace(sc, Ray{trianglePoint, toLight}, &c.cnt, c.bvh, true, &c.nodes).found) continue;
     V3 bsdf = evaluateColorResponse(mat, c.M, hitNormal, toLight, -ray.d);
     V3 radiance = evaluateLight(L, trianglePoint);
     color = color + radiance * bsdf;
@@ -382,7 +526,7 @@ inline V3 integrate(Ctx& c, Engine& e, Ray ray, int mode, int finalDepth, bool& 
   if (maxv > 8) maxv = 8;
   for (int depth = 0; depth < maxv; depth++) {
     c.cnt.closest++;
-    Hit h = rayTrace(c.sc, ray, &c.cnt);
+    Hit h = rayTrace(c.sc, ray, &c.cnt, c.bvh, false, &c.nodes);
     if (!(h.found && h.d > 0.f)) {
       if (depth == 0) found = false;
       break;
@@ -406,6 +550,7 @@ struct Emitter {
   const rt_scene_desc& sc;
   Math M;
   Counters* cnt;
+  const OBvh* bvh;
   // one photon; returns true and fills `out` if a particle is stored
   bool trace(Engine& e, Ray ray, float weight, Photon& out) {
     Photon ph{};
@@ -418,7 +563,7 @@ struct Emitter {
       }
       if (depth >= 20) return false;
       if (cnt) cnt->closest++;
-      Hit h = rayTrace(sc, ray, cnt);
+      Hit h = rayTrace(sc, ray, cnt, bvh);
       if (!(h.found && h.d > 0.f)) {
         if (depth != 0) {
           out = ph;
@@ -448,11 +593,12 @@ struct Emitter {
 
 // legacy: one engine threaded through; pixel: one stream per emitted photon
 void emitPhotons(const rt_scene_desc& sc, const Math& M, int numOfPhotons, int rng_mode,
-                 uint32_t seed, Engine* legacy, std::vector<Photon>& list, Counters* cnt) {
+                 uint32_t seed, Engine* legacy, std::vector<Photon>& list, Counters* cnt,
+                 const OBvh* bvh = nullptr) {
   if (numOfPhotons <= 0 || sc.n_lights == 0) return;
   float lightPdf = 1.f / (float)sc.n_lights;
   int perLS = (int)((float)numOfPhotons * lightPdf);
-  Emitter em{sc, M, cnt};
+  Emitter em{sc, M, cnt, bvh};
   for (uint32_t li = 0; li < sc.n_lights; li++) {
     const rt_light& L = sc.lights[li];
     V3 lsNormal = ld3(L.normal);
@@ -484,6 +630,7 @@ typedef struct orc_opts {
   const float* ext_photons; // optional [n][7] (pos, dir, w) ALREADY in kd order
   uint32_t n_ext_photons;
   uint32_t engine_state;    // legacy: initial engine state (1 = default seed)
+  uint32_t accel;           // 0 = the reference's exhaustive loop, 1 = OBvh (same results)
 } orc_opts;
 
 // Whole Renderer::render (Renderer.cpp:203-272) on the flat scene.  accum_out
@@ -496,6 +643,10 @@ int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
   Engine legacy{o && o->engine_state ? o->engine_state : 1u};
   Counters total;
   KdTree tree;
+  OBvh obvh;
+  const OBvh* bvh = nullptr;
+  if (o && o->accel == 1) obvh.build(*sc), bvh = &obvh;
+  uint64_t nodesTotal = 0;
   const int world = p->world ? (int)p->world : 1;
   const uint32_t tile = p->tile ? p->tile : 8;
   if (o && o->ext_photons && o->n_ext_photons) {
@@ -504,7 +655,7 @@ int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
   } else if (p->use_photons && p->photons_requested > 0) {
     // Renderer.cpp:209-213: photon map + kd-tree are built inside render()
     emitPhotons(*sc, M, (int)p->photons_requested, p->rng_mode, p->seed, &legacy, tree.nodes,
-                &total);
+                &total, bvh);
     tree.build();
   }
   std::vector<float> acc((size_t)w * h * 4, 0.f);
@@ -529,17 +680,18 @@ int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
     return (int)((tx + ty) % (uint32_t)world) == (int)p->rank;
   };
   if (p->rng_mode == RT_RNG_LEGACY) {
-    Ctx c{*sc, M, &tree, (int)p->k, (int)p->photons_requested, Counters()};
+    Ctx c{*sc, M, &tree, (int)p->k, (int)p->photons_requested, Counters(), bvh};
     for (uint32_t i = s0; i < s1; i++)
       for (uint32_t y = 0; y < h; y++)
         for (uint32_t x = 0; x < w; x++) sample(c, legacy, x, y, i);
     total.closest += c.cnt.closest, total.shadow += c.cnt.shadow, total.knn += c.cnt.knn;
     total.tri_tests += c.cnt.tri_tests, total.kd_visited += c.cnt.kd_visited;
+    nodesTotal += c.nodes;
   } else {
     int nth = o && o->threads > 0 ? o->threads : omp_get_max_threads();
 #pragma omp parallel num_threads(nth)
     {
-      Ctx c{*sc, M, &tree, (int)p->k, (int)p->photons_requested, Counters()};
+      Ctx c{*sc, M, &tree, (int)p->k, (int)p->photons_requested, Counters(), bvh};
 #pragma omp for schedule(dynamic, 4)
       for (int64_t y = 0; y < (int64_t)h; y++)
         for (uint32_t x = 0; x < w; x++) {
@@ -553,6 +705,7 @@ int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
       {
         total.closest += c.cnt.closest, total.shadow += c.cnt.shadow, total.knn += c.cnt.knn;
         total.tri_tests += c.cnt.tri_tests, total.kd_visited += c.cnt.kd_visited;
+        nodesTotal += c.nodes;
       }
     }
   }
@@ -575,6 +728,28 @@ int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
     stats->knn_queries = total.knn;
     stats->tris_tested = total.tri_tests;
     stats->kd_visited = total.kd_visited;
+    stats->nodes_visited = nodesTotal;
+  }
+  return RT_OK;
+}
+
+// accel: 0 = exhaustive loop, 1 = OBvh; kind: RT_TRACE_CLOSEST / RT_TRACE_ANY (only `hit` is set)
+int orc_trace2(const rt_scene_desc* sc, const rt_ray* rays, uint32_t n, rt_hit* hits, uint32_t accel, uint32_t kind) {
+  OBvh obvh;
+  const OBvh* bvh = nullptr;
+  if (accel == 1) obvh.build(*sc), bvh = &obvh;
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < (int64_t)n; i++) {
+    Hit h = rayTrace(*sc, Ray{ld3(rays[i].origin), ld3(rays[i].direction)}, nullptr, bvh, bvh && kind == RT_TRACE_ANY);
+    rt_hit& o = hits[i];
+    memset(&o, 0, sizeof(o));
+    o.hit = h.found;
+    if (h.found && kind != RT_TRACE_ANY) {
+      o.mesh = h.mesh;
+      o.tri = h.tri - sc->mesh_tri_begin[h.mesh];
+      for (int j = 0; j < 3; j++) o.vtx[j] = sc->tri_vtx[3 * (size_t)h.tri + j] - sc->mesh_vtx_begin[h.mesh];
+      o.u = h.u, o.v = h.v, o.d = h.d;
+    }
   }
   return RT_OK;
 }

@@ -444,7 +444,19 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
       out.trisRef[t] = makeRec(sc, t, m);
     }
   }
-  out.pad = 6e-5f * std::max(1.f, maxAbs);
+  // The padding must dominate the float triangle test's own error, which grows with the
+  // distance of the ray ORIGIN from the geometry (tvec = o - p0 rounds to ulp(|o|)): the
+  // origins the integrator uses are the camera, the lights (photon emission) and surface
+  // points, so they all enter the reference magnitude.  rt_trace rays from farther away
+  // than originBound run the exhaustive loop instead (k_trace).
+  float padRef = std::max(1.f, maxAbs);
+  for (int a = 0; a < 3; ++a)
+    if (std::isfinite(sc.camera.position[a])) padRef = std::max(padRef, std::fabs(sc.camera.position[a]));
+  for (uint32_t l = 0; l < sc.n_lights; ++l)
+    for (int a = 0; a < 3; ++a)
+      if (std::isfinite(sc.lights[l].position[a])) padRef = std::max(padRef, std::fabs(sc.lights[l].position[a]));
+  out.pad = 6e-5f * padRef;
+  out.originBound = 16.f * padRef;
 
   // threads: 0 = one per hardware thread (at most 16).  The top 6 levels fork.
   uint32_t nthreads = threads ? threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));

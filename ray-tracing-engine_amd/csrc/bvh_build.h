@@ -5,8 +5,9 @@
 // (SURVEY.md §0.2, App. A.4), so nothing of it is reproduced.  This is our own
 // design for gfx950:
 //   * ONE binary BVH over all meshes (not one pointer tree per mesh);
-//   * 64-byte node records holding BOTH child boxes, so a lane fetches one
-//     128-B-line-aligned record per step and never touches a child it culls;
+//   * node records holding BOTH child boxes, so a lane fetches one record per step and
+//     never touches a child it culls — built as 64-byte float records (Node: tests,
+//     export) and traversed as 32-byte binary16-packed records (Node16, see below);
 //   * 48-byte triangle records (p0, e1, e2, global id, mesh) stored in leaf
 //     order, so a leaf is 1..leaf_max consecutive records;
 //   * boxes padded by an absolute epsilon and a depth bound, so the LDS
@@ -65,6 +66,7 @@ struct Built {
   std::vector<TriRec> trisRef;  // reference order (brute-force kernel)
   uint32_t maxDepth = 0, leafMax = 2;
   float pad = 0.f;
+  float originBound = 0.f;      // ray origins with a larger |coordinate| are outside the padding analysis
 };
 
 // Throws std::runtime_error on an inconsistent scene description.

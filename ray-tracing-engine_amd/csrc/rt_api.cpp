@@ -297,6 +297,7 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
   S.n_lights = sc->n_lights;
   S.n_photons = 0;
   S.invBoxScale = 1.f / c->bvh.boxScale;
+  S.originBound = c->bvh.originBound;
   // descent early-exit threshold (Trav::round); measured C2 / C4 / C5 Grays/s:
   // 0 (off) 12.8 / 10.7 / 3.28, 8: 13.9 / - / -, 16: 13.7 / 12.0 / 4.00, 32: 13.0 / - / 4.02
   S.leafT = getenv("RT_LEAFT") ? atoi(getenv("RT_LEAFT")) : 12;
@@ -337,9 +338,13 @@ int rt_set_photons(rt_ctx* c, const float* pos3, const float* dir3, uint32_t n) 
   if (n && (!pos3 || !dir3)) return fail(RT_ERR_INVALID, "photon arrays are null");
   if (n >= (1u << 30)) return fail(RT_ERR_UNSUPPORTED, "too many photons");
   HIP_TRY(hipSetDevice(c->device));
-  if (c->phPos) HIP_TRY(hipFree(c->phPos));
-  if (c->phDir) HIP_TRY(hipFree(c->phDir));
+  // the device scene forgets the old map BEFORE it is freed: a failed upload must leave
+  // "no photons" behind (check_params then refuses use_photons), never dangling pointers
+  c->S.phPos = c->S.phDir = nullptr, c->S.n_photons = 0;
+  float4 *oldP = c->phPos, *oldD = c->phDir;
   c->phPos = c->phDir = nullptr;
+  if (oldP) HIP_TRY(hipFree(oldP));
+  if (oldD) HIP_TRY(hipFree(oldD));
   std::vector<float4> p(n), d(n);
   for (uint32_t i = 0; i < n; ++i) {
     p[i] = make_float4(pos3[3 * (size_t)i], pos3[3 * (size_t)i + 1], pos3[3 * (size_t)i + 2], 0.f);
@@ -347,7 +352,12 @@ int rt_set_photons(rt_ctx* c, const float* pos3, const float* dir3, uint32_t n) 
   }
   int rc = upload(&c->phPos, p.data(), n);
   if (rc == RT_OK) rc = upload(&c->phDir, d.data(), n);
-  if (rc != RT_OK) return rc;
+  if (rc != RT_OK) {  // drop whatever half of the map made it
+    if (c->phPos) (void)hipFree(c->phPos);
+    if (c->phDir) (void)hipFree(c->phDir);
+    c->phPos = c->phDir = nullptr;
+    return rc;
+  }
   c->S.phPos = c->phPos, c->S.phDir = c->phDir, c->S.n_photons = n;
   return RT_OK;
 }
@@ -613,9 +623,9 @@ int rt_profile_collect(rt_ctx* c, double* total_ms, uint32_t* launches) {
 }
 
 int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint32_t n) {
-  static const uint32_t inBytes[] = {8, 4, 4, 16, 60, 68, 56, 96, 112};
-  static const uint32_t outBytes[] = {8, 4, 4, 4, 16, 12, 24, 12, 48};
-  if (which > RT_UNIT_SAMPLERS) return fail(RT_ERR_INVALID, "unknown unit %u", which);
+  static const uint32_t inBytes[] = {8, 4, 4, 16, 60, 68, 56, 96, 112, 88, 8};
+  static const uint32_t outBytes[] = {8, 4, 4, 4, 16, 12, 24, 12, 48, 16, 16};
+  if (which > RT_UNIT_POW) return fail(RT_ERR_INVALID, "unknown unit %u", which);
   if (n && (!in || !out)) return fail(RT_ERR_INVALID, "null argument");
   if (n == 0) return RT_OK;
   int rc = select_device(device);

@@ -41,6 +41,7 @@ struct DevScene {
   const float4* phDir;     // income direction xyz + weight
   uint32_t n_tris, n_nodes, n_lights, n_photons;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
+  float originBound;       // k_trace: rays starting farther out run the exhaustive loop (rtbvh::Built)
   uint32_t leafT;          // Trav::round leaves its descent when fewer lanes than this still descend
   uint32_t refillT;        // vertex_pool hands out rays once this many workers are free
   uint32_t stealT;         // ... and splits the stacks of the last long rays once this many are free

@@ -1,13 +1,15 @@
 // rt_kernels.hip — gfx950 kernels of the path-tracing hot path.
 //
 // Execution model (wave64, CDNA4):
-//   * one lane = one pixel; a wave owns an 8x8 pixel tile and walks the samples
-//     i = s0..s1-1 of its pixels in order, so every pixel's float sum is formed in
-//     exactly the order the reference forms it (Renderer.cpp:219-258) whatever the
-//     number of launches / GPUs the frame is split over;
+//   * one workgroup = one wave; one lane = one (pixel, sample) pair: a wave integrates
+//     S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side and the
+//     pixel's owner lane adds them in sample order, so every pixel's float sum is formed
+//     in exactly the order the reference forms it (Renderer.cpp:219-258) whatever S, the
+//     number of launches or the number of GPUs the frame is split over;
 //   * BVH traversal keeps a per-lane stack in LDS laid out [level][thread]
 //     (ds_read/write_b32, lane-contiguous => bank-conflict free), node records are
-//     64 B (4 x dwordx4 per lane per step), triangle records 48 B (3 x dwordx4);
+//     32 B (12 binary16 box planes + 2 child refs: 2 x dwordx4 per lane per step),
+//     triangle records 48 B (3 x dwordx4);
 //   * the photon k-NN keeps its k-heap in LDS ([slot][thread]) and re-uses the
 //     traversal stack region for the kd-tree's per-level split distances;
 //   * no inter-workgroup communication, no barriers: every wave is independent,
@@ -904,7 +906,13 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, const rt_ray* __res
   if (i < n) {
     HitRec h;
     const f3 o = ld(rays[i].origin), d = ld(rays[i].direction);
-    const bool found = cast<BRUTE, ANY, true>(S, true, o, d, lds + threadIdx.x, h, st);
+    // origins beyond the range the box padding was derived for (bvh_build.cpp: camera,
+    // lights, geometry) are outside the exactness argument of the slab test: those rays
+    // take the exhaustive loop (a NaN origin compares false and stays on the BVH path,
+    // which ends it at once)
+    const bool far = !BRUTE && fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) > S.originBound;
+    bool found = cast<BRUTE, ANY, true>(S, !far, o, d, lds + threadIdx.x, h, st);
+    if (far) found = brute<ANY, true>(S, o, d, h, st);
     rt_hit r;
     r.hit = found, r.mesh = 0, r.tri = 0, r.vtx[0] = r.vtx[1] = r.vtx[2] = 0, r.u = r.v = r.d = 0.f;
     if (found && !ANY) {
@@ -1069,6 +1077,22 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
       o[2] = h.x, o[3] = h.y, o[4] = h.z, o[5] = p.x, o[6] = p.y, o[7] = p.z;
       ((uint32_t*)o)[8] = g.s;
       o[9] = o[10] = o[11] = 0.f;
+      break;
+    }
+    case RT_UNIT_LIGHT_SAMPLE: {  // in (22 words): state, rt_light(21 floats); out: sample3, end state
+      const uint32_t* a = (const uint32_t*)in + 22 * (size_t)i;
+      Rng g{a[0]};
+      rt_light l;
+      memcpy(&l, a + 1, sizeof(rt_light));
+      const f3 p = light_sample(g, l);
+      float* o = (float*)out + 4 * (size_t)i;
+      o[0] = p.x, o[1] = p.y, o[2] = p.z;
+      ((uint32_t*)o)[3] = g.s;
+      break;
+    }
+    case RT_UNIT_POW: {  // in: double x; out: double rt_pow2(x), rt_pow5(x)
+      const double x = ((const double*)in)[i];
+      ((double*)out)[2 * (size_t)i] = rt_pow2(x), ((double*)out)[2 * (size_t)i + 1] = rt_pow5(x);
       break;
     }
     default:

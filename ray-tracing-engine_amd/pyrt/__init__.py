@@ -21,7 +21,7 @@ RNG_LEGACY, RNG_PIXEL = 0, 1
 ACCEL_BVH, ACCEL_BRUTE = 0, 1
 TRACE_CLOSEST, TRACE_ANY = 0, 1
 (UNIT_ASIN, UNIT_SINF, UNIT_COSF, UNIT_STREAM_SEED, UNIT_TRIANGLE, UNIT_BSDF, UNIT_RAY_AT, UNIT_LIGHT_EVAL,
- UNIT_SAMPLERS) = range(9)
+ UNIT_SAMPLERS, UNIT_LIGHT_SAMPLE, UNIT_POW) = range(11)
 KMAX = 16
 
 
@@ -184,10 +184,16 @@ class Scene:
         self.desc_ptr = host().rt_host_scene_desc(h)
         self.desc = self.desc_ptr.contents
 
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _host is not None:
+            _host.rt_host_scene_free(h)
+
     def __del__(self):
-        if getattr(self, "_h", None) and host is not None:  # (module globals are gone at interpreter exit)
-            host().rt_host_scene_free(self._h)
-            self._h = None
+        try:  # at interpreter exit module globals / ctypes may already be torn down
+            self.close()
+        except Exception:
+            pass
 
     def arrays(self):
         d = self.desc
@@ -316,7 +322,8 @@ _UNIT_IO = {UNIT_ASIN: (np.float64, 1, np.float64, 1), UNIT_SINF: (np.float32, 1
             UNIT_COSF: (np.float32, 1, np.float32, 1), UNIT_STREAM_SEED: (np.uint32, 4, np.uint32, 1),
             UNIT_TRIANGLE: (np.float32, 15, np.float32, 4), UNIT_BSDF: (np.float32, 17, np.float32, 3),
             UNIT_RAY_AT: (np.float32, 14, np.float32, 6), UNIT_LIGHT_EVAL: (np.float32, 24, np.float32, 3),
-            UNIT_SAMPLERS: (np.uint32, 28, np.uint32, 12)}
+            UNIT_SAMPLERS: (np.uint32, 28, np.uint32, 12), UNIT_LIGHT_SAMPLE: (np.uint32, 22, np.uint32, 4),
+            UNIT_POW: (np.float64, 1, np.float64, 2)}
 
 
 def unit(which, inp, out_init=None, device=0):

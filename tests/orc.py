@@ -16,7 +16,7 @@ MATH_LIBM, MATH_DET = 0, 1
 
 class Opts(C.Structure):
     _fields_ = [("math_mode", C.c_int32), ("threads", C.c_int32), ("ext_photons", C.c_void_p),
-                ("n_ext_photons", C.c_uint32), ("engine_state", C.c_uint32)]
+                ("n_ext_photons", C.c_uint32), ("engine_state", C.c_uint32), ("accel", C.c_uint32)]
 
 
 _lib = None
@@ -29,6 +29,7 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(pyrt.SceneDesc), C.POINTER(pyrt.Params), C.POINTER(Opts), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.POINTER(pyrt.Stats)]
         L.orc_trace.argtypes = [C.POINTER(pyrt.SceneDesc), C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_trace2.argtypes = [C.POINTER(pyrt.SceneDesc), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
         L.orc_emit_photons.argtypes = [C.POINTER(pyrt.SceneDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
                                        C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                        C.POINTER(C.c_uint64)]
@@ -76,11 +77,15 @@ def background(w, h):
     return bg
 
 
-def render(scene, params, math_mode=MATH_LIBM, threads=0, ext_photons=None, bg=None, engine_state=1):
-    """Returns (out_rgb or None, accum[h,w,4], stats)."""
+ACCEL_LOOP, ACCEL_OBVH = 0, 1
+
+
+def render(scene, params, math_mode=MATH_LIBM, threads=0, ext_photons=None, bg=None, engine_state=1, accel=ACCEL_LOOP):
+    """Returns (out_rgb or None, accum[h,w,4], stats).  accel=ACCEL_OBVH runs the same
+    restatement over the oracle's own CPU BVH (identical results, see rt_oracle.cpp OBvh)."""
     w, h = params.width, params.height
     o = Opts()
-    o.math_mode, o.threads, o.engine_state = math_mode, threads, engine_state
+    o.math_mode, o.threads, o.engine_state, o.accel = math_mode, threads, engine_state, accel
     keep = None
     if ext_photons is not None:
         keep = np.ascontiguousarray(ext_photons, np.float32).reshape(-1, 7)
@@ -95,10 +100,13 @@ def render(scene, params, math_mode=MATH_LIBM, threads=0, ext_photons=None, bg=N
     return out, acc, st
 
 
-def trace(scene, rays):
+def trace(scene, rays, accel=ACCEL_LOOP, kind=pyrt.TRACE_CLOSEST):
     rays = np.ascontiguousarray(rays, pyrt.RAY_DTYPE)
     hits = np.zeros(len(rays), pyrt.HIT_DTYPE)
-    lib().orc_trace(scene.desc_ptr, _p(rays), len(rays), _p(hits))
+    if accel == ACCEL_LOOP and kind == pyrt.TRACE_CLOSEST:
+        lib().orc_trace(scene.desc_ptr, _p(rays), len(rays), _p(hits))
+    else:
+        lib().orc_trace2(scene.desc_ptr, _p(rays), len(rays), _p(hits), accel, kind)
     return hits
 
 

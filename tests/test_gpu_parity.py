@@ -139,38 +139,49 @@ def test_jitter_and_light_sample_golden(golden, cubes):
         for _ in range(4):
             orc.lib().orc_engine_next(C.byref(st))
         state = st.value
+    # LightSource.h:46-49 randAreaPosition: 4 rounds over the 3 lights from a fresh seed-1
+    # engine, each call continuing the engine where the previous one left it
+    state = 1
+    for j, row in enumerate(np.array(V["randAreaPosition_seq"], np.uint32).reshape(-1, 3)):
+        inp = np.zeros((1, 22), np.uint32)
+        inp[0, 0], inp[0, 1:22] = state, lights[j % 3]
+        out = pyrt.unit(pyrt.UNIT_LIGHT_SAMPLE, inp)[0]
+        assert np.array_equal(out[0:3], row), j
+        state = int(out[3])
+    st = C.c_uint32(1)
+    for _ in range(2 * 12):  # 2 float draws per call = 1 engine call each
+        orc.lib().orc_engine_next(C.byref(st))
+    assert state == st.value
+
+
+def test_detmath_ulp_bounds_vs_libm():
+    """include/rt_pixelmode.h is shared by the oracle and the device, so GPU-vs-oracle
+    parity cannot see a defect in it: bound every pinned function against libm (numpy,
+    float64 reference) on the GPU.  Stated tolerances: asin within 4 ulp(double) and its
+    float narrowing within 1 ulp(float); pow2 exact, pow5 = (x*x)*(x*x)*x within 3
+    ulp(double) (three roundings), both equal to libm after the narrowing to float the
+    reference performs (sin/cos: 1.2e-7 absolute, test above)."""
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.uniform(0, 1, 300000), 1 - 10.0 ** rng.uniform(-12, -1, 50000), 10.0 ** rng.uniform(-12, -1, 50000),
+                        [0.0, 1.0, 0.5]])
+    got = pyrt.unit(pyrt.UNIT_ASIN, x)[:, 0]
+    ref = np.arcsin(x)
+    # double result: relative error below 4 ulp(double); after the narrowing the reference does
+    # (RayTracer.h:102 `float theta = asin(..)`) at most one float ulp, and equal for > 99.9999 %
+    assert np.abs(got - ref).max() <= 4 * np.spacing(ref).max()
+    gf, rf = got.astype(np.float32), ref.astype(np.float32)
+    assert (np.abs(gf.view(np.int32).astype(np.int64) - rf.view(np.int32).astype(np.int64)) <= 1).all()
+    assert (gf != rf).mean() < 1e-6
+    y = np.concatenate([rng.uniform(0, 1, 300000), rng.uniform(1, 2, 50000), [0.0, 1.0, 2.0]])
+    pw = pyrt.unit(pyrt.UNIT_POW, y)
+    for col, e, ulps in ((0, 2.0, 0), (1, 5.0, 3)):
+        r = np.power(y, e)
+        assert (np.abs(pw[:, col] - r) <= ulps * np.spacing(r)).all()
+        assert (pw[:, col].astype(np.float32) != r.astype(np.float32)).mean() < 1e-6
 
 
 # ------------------------------------------------------------------ closest hit / any hit
-def _ray_batch(scene, n, seed):
-    """Camera rays, rays leaving surface points exactly (no epsilon), random rays,
-    axis-parallel rays (zero direction components) and a NaN ray."""
-    rng = np.random.default_rng(seed)
-    a = scene.arrays()
-    rays = np.zeros(n, pyrt.RAY_DTYPE)
-    cam = a["camera"]
-    u, v = rng.random(n, np.float32), rng.random(n, np.float32)
-    d = cam[1] + u[:, None] * cam[2] + v[:, None] * cam[3] - cam[0]
-    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
-    rays["origin"], rays["direction"] = cam[0], d.astype(np.float32)
-    # surface starts: barycentric points of random triangles
-    m = n // 2
-    t = rng.integers(0, len(a["tri"]), m)
-    b = rng.random((m, 2), np.float32)
-    b[b.sum(1) > 1] = 1 - b[b.sum(1) > 1]
-    P = a["pos"][a["tri"][t]]
-    w = (1 - b[:, 0] - b[:, 1]).astype(np.float32)
-    pts = w[:, None] * P[:, 0] + b[:, 0:1] * P[:, 1] + b[:, 1:2] * P[:, 2]
-    rays["origin"][:m] = pts.astype(np.float32)
-    dirs = rng.normal(size=(m, 3)).astype(np.float32)
-    dirs[::3] /= np.linalg.norm(dirs[::3], axis=1, keepdims=True)
-    dirs[1::5] = (np.array([0.0, -0.3, 1.1], np.float32) - pts[1::5]).astype(np.float32)  # towards light 2
-    rays["direction"][:m] = dirs
-    q = n // 16
-    rays["direction"][m:m + q] = rng.choice(np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 1, 1], [-1, 0, 1]], np.float32), q)
-    rays["origin"][m:m + q] = rng.uniform(-1.4, 1.4, (q, 3)).astype(np.float32)
-    rays["direction"][m + q] = np.nan
-    return rays
+from raybatch import ray_batch as _ray_batch  # noqa: E402
 
 
 @pytest.mark.parametrize("which", ["cubes", "lowres"])
