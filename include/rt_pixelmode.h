@@ -172,4 +172,19 @@ RT_HD float rt_cosf(float x) {
   return (float)v;
 }
 
+/* Both at once: one argument reduction, each kernel polynomial evaluated once, results
+ * selected by quadrant — the same operations on the same operands as rt_sinf(x) and
+ * rt_cosf(x), so the same bits (the device uses this form: no divergent quadrant
+ * branches, half the double-precision work). */
+RT_HD void rt_sincosf(float x, float* s, float* c) {
+  int q;
+  double r = rt_reduce_pio2(x, &q);
+  double ks = rt_ksin(r), kc = rt_kcos(r);
+  double sv = (q & 1) ? kc : ks, cv = (q & 1) ? ks : kc;
+  if (q & 2) sv = -sv;
+  if (q == 1 || q == 2) cv = -cv;
+  *s = (float)sv;
+  *c = (float)cv;
+}
+
 #endif /* RT_PIXELMODE_H */

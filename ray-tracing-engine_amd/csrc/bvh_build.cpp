@@ -405,6 +405,60 @@ struct Rotator {
 
 }  // namespace
 
+// Final node numbering: the kTop nodes a ray is most likely to visit first — taken
+// greedily by box surface area from the root, so the set is closed under "parent of" and
+// every prefix [0, K) of it is itself such a set — then the remaining subtrees in
+// pre-order.  The render kernel keeps a prefix of the array in LDS (one copy per CU,
+// rt_kernels.hip k_render_persist); which K it picks depends on the LDS left over.
+static void relayoutTop(std::vector<Node>& nodes, uint32_t kTop) {
+  const uint32_t n = static_cast<uint32_t>(nodes.size());
+  if (n <= 2) return;
+  auto area = [](const float* lo, const float* hi) {
+    const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  struct Item {
+    double a;
+    int32_t idx;
+    bool operator<(const Item& o) const { return a < o.a || (a == o.a && idx > o.idx); }  // max-heap, low index first
+  };
+  std::vector<int32_t> newOf(n, -1);
+  std::vector<Item> heap;
+  heap.push_back({1e300, 0});
+  uint32_t next = 0;
+  while (!heap.empty() && next < kTop) {
+    std::pop_heap(heap.begin(), heap.end());
+    const Item it = heap.back();
+    heap.pop_back();
+    newOf[it.idx] = static_cast<int32_t>(next++);
+    const Node& nd = nodes[it.idx];
+    if (nd.child[0] >= 0) heap.push_back({area(nd.lo0, nd.hi0), nd.child[0]}), std::push_heap(heap.begin(), heap.end());
+    if (nd.child[1] >= 0) heap.push_back({area(nd.lo1, nd.hi1), nd.child[1]}), std::push_heap(heap.begin(), heap.end());
+  }
+  // the subtrees hanging below the top, largest first, each in pre-order
+  std::sort(heap.begin(), heap.end(), [](const Item& x, const Item& y) { return y < x; });
+  std::vector<int32_t> st;
+  for (const Item& r : heap) {
+    st.push_back(r.idx);
+    while (!st.empty()) {
+      const int32_t i = st.back();
+      st.pop_back();
+      newOf[i] = static_cast<int32_t>(next++);
+      if (nodes[i].child[1] >= 0) st.push_back(nodes[i].child[1]);
+      if (nodes[i].child[0] >= 0) st.push_back(nodes[i].child[0]);
+    }
+  }
+  if (next != n) throw std::runtime_error("internal error: relayout lost nodes");
+  std::vector<Node> out(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Node nd = nodes[i];
+    for (int c = 0; c < 2; ++c)
+      if (nd.child[c] >= 0) nd.child[c] = newOf[nd.child[c]];
+    out[newOf[i]] = nd;
+  }
+  nodes.swap(out);
+}
+
 void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threads) {
   if (leafMax == 0) leafMax = 2;  // measured on C2: 2 -> 7.35, 3 -> 7.26, 4 -> 6.63, 8 -> 4.9 Grays/s
   if (leafMax > 8) leafMax = 8;
@@ -498,6 +552,7 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
       out.maxDepth = R.height[0];  // (index 0 is the root before and after the relayout)
     }
   }
+  relayoutTop(out.nodes, kTopNodes);
   out.tris.resize(sc.n_triangles);
   for (uint32_t i = 0; i < sc.n_triangles; ++i) out.tris[i] = out.trisRef[B.prims[i].id];
 

@@ -55,6 +55,7 @@ struct alignas(16) TriRec { // 48 B
 static_assert(sizeof(TriRec) == 48, "triangle record must be 48 bytes");
 
 constexpr int kMaxDepth = 32;      // traversal stack entries per lane
+constexpr uint32_t kTopNodes = 4096;  // nodes [0, kTopNodes) are the most-visited top of the tree (LDS candidates)
 
 inline int32_t encodeLeaf(uint32_t first, uint32_t count) { return ~static_cast<int32_t>((first << 3) | (count - 1)); }
 

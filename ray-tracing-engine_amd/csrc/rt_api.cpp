@@ -91,6 +91,8 @@ struct rt_ctx {
   uint32_t nTiles = 0;
   TileKey tileKey;
   unsigned long long* dCounters = nullptr;
+  uint32_t* dTileCounter = nullptr;  // work queue head of the persistent render kernel
+  uint32_t numCUs = 0;
   hipEvent_t ev[kEventPairs][2];
   int evUsed = 0;
   bool evReady = false;
@@ -200,6 +202,12 @@ int read_counters(rt_ctx* c, rt_stats* st) {
   st->reserved[1] = h[RTK_CNT_WLEAF];  // wave-level leaf phases -> lane utilisation of the traversal
   st->reserved[2] = h[RTK_CNT_LWAIT];  // lanes holding a leaf / lanes without a ray at the START of the round,
   st->reserved[3] = h[RTK_CNT_LIDLE];  // summed over that round's node steps
+#ifdef RT_PHASE_TIMING  // diagnostic build (tools/phase_timing.sh): section clocks of the pooled kernel
+  if (getenv("RT_PHASE_DUMP")) {
+    fprintf(stderr, "{\"phase_clocks\": [");
+    for (int i = 16; i < RTK_CNT_COUNT; ++i) fprintf(stderr, "%llu%s", h[i], i + 1 < RTK_CNT_COUNT ? ", " : "]}\n");
+  }
+#endif
   return RT_OK;
 }
 
@@ -230,7 +238,9 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
     while ((1ull << kd) <= c->S.n_photons) ++kd;
     levels = levels > kd + 1 ? levels : kd + 1;
   }
-  A.stackLevels = levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels;
+  // (+1: row 0 of a lane's stack is the TERM sentinel, rt_kernels.hip Trav)
+  A.stackLevels = (levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels) + 1u;
+  A.tileCounter = c->dTileCounter, A.numCUs = c->numCUs, A.waveWords = 0;
   const int e = c->evUsed % kEventPairs;
   HIP_TRY(hipEventRecord(c->ev[e][0], stream));
   hipError_t he = rtk::launch_render(p->accel == RT_ACCEL_BRUTE, p->use_photons != 0, p->collect_stats != 0, c->S, A,
@@ -304,7 +314,16 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
   S.stealT = getenv("RT_STEALT") ? atoi(getenv("RT_STEALT")) : 8;
   S.refillT = getenv("RT_REFILLT") ? atoi(getenv("RT_REFILLT")) : 24;  // measured C2: 1 -> 15.9, 8 -> 16.0, 16 -> 16.1, 32 -> 16.2 Grays/s
   S.phPos = S.phDir = nullptr;
+  S.topK = 0;
   S.cam = sc->camera;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->numCUs = (uint32_t)cus;
+    if (hipMalloc(reinterpret_cast<void**>(&c->dTileCounter), sizeof(uint32_t)) != hipSuccess) {
+      rt_destroy(c);
+      return fail(RT_ERR_HIP, "tile counter allocation failed");
+    }
+  }
   if (hipMalloc(reinterpret_cast<void**>(&c->dCounters), RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(c->dCounters, 0, RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess) {
     rt_destroy(c);
@@ -328,6 +347,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->phDir) (void)hipFree(c->phDir);
   if (c->dTiles) (void)hipFree(c->dTiles);
   if (c->dCounters) (void)hipFree(c->dCounters);
+  if (c->dTileCounter) (void)hipFree(c->dTileCounter);
   if (c->evReady)
     for (auto& pr : c->ev) (void)hipEventDestroy(pr[0]), (void)hipEventDestroy(pr[1]);
   delete c;

@@ -104,8 +104,11 @@ RT_DEV f3 hemisphere_sample(Rng& g, f3 normal) {
   v2 = unit3(v2);
   float theta = (float)rt_asin(g.uniformD(0.0, hi));
   float phi = (float)(2 * PI * g.uniformD(0.0, hi));
-  f3 dir = unit3(v1 * rt_cosf(phi) + v2 * rt_sinf(phi));
-  return unit3(normal * rt_cosf(theta) + dir * rt_sinf(theta));
+  float sp, cp, st, ct;
+  rt_sincosf(phi, &sp, &cp);
+  rt_sincosf(theta, &st, &ct);
+  f3 dir = unit3(v1 * cp + v2 * sp);
+  return unit3(normal * ct + dir * st);
 }
 
 // ------------------------------------------------------------------ camera / lights

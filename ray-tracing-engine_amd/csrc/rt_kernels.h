@@ -20,7 +20,7 @@ enum {
   RTK_CNT_WLEAF,  // wave-level leaf phases
   RTK_CNT_LWAIT,  // lanes holding a leaf, summed over the wave-level node steps
   RTK_CNT_LIDLE,  // lanes without a ray, summed over the wave-level node steps
-  RTK_CNT_COUNT = 12
+  RTK_CNT_COUNT = 32  // [16..31]: section clocks of the diagnostic build (RT_PHASE_TIMING)
 };
 
 namespace rtk {
@@ -41,6 +41,7 @@ struct DevScene {
   const float4* phDir;     // income direction xyz + weight
   uint32_t n_tris, n_nodes, n_lights, n_photons;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
+  uint32_t topK;           // node records [0, topK) are LDS-resident in the persistent kernel (set per launch)
   float originBound;       // k_trace: rays starting farther out run the exhaustive loop (rtbvh::Built)
   uint32_t leafT;          // Trav::round leaves its descent when fewer lanes than this still descend
   uint32_t refillT;        // vertex_pool hands out rays once this many workers are free
@@ -56,6 +57,10 @@ struct RenderArgs {
   uint32_t stackLevels;   // LDS traversal-stack entries per lane (BVH depth; kd depth + 1 with photons)
   uint32_t sshift;        // a wave = (64 >> sshift) pixels x (1 << sshift) samples side by side
   uint32_t tileW, tileH;  // pixel footprint of one wave (tileW * tileH == 64 >> sshift)
+  // persistent pooled kernel (k_render_persist)
+  uint32_t* tileCounter;  // next wave tile to hand out (zeroed before the launch)
+  uint32_t waveWords;     // LDS words per wave (stack levels x 64 + pool), set by the launcher
+  uint32_t numCUs;        // workgroups to launch (one per CU)
 };
 
 hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,

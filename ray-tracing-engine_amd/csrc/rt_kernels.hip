@@ -36,6 +36,25 @@ struct Lds {
   uint2* heap;      // [KMAX][BLOCK] {distance bits, photon index}
 };
 
+// Diagnostic build only (-DRT_PHASE_TIMING, tools/phase_timing.sh): wave-level shader-clock
+// time per section of the pooled k_render, accumulated in LDS by lane 0 at wave-uniform
+// points and flushed to counters[16..].  Never compiled into the product library.
+#ifdef RT_PHASE_TIMING
+__shared__ unsigned long long g_phAcc[24];
+__shared__ unsigned long long g_phT0;
+#define PH(p)                                                  \
+  do {                                                         \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0) g_phAcc[p] += t_ - g_phT0, g_phT0 = t_; \
+  } while (0)
+#define PHC(p) do { if (threadIdx.x == 0) g_phAcc[p] += 1; } while (0)
+#else
+#define PH(p) do { } while (0)
+#define PHC(p) do { } while (0)
+#endif
+enum { PH_SETUP = 0, PH_PRIMARY, PH_VSETUP, PH_FILL, PH_HANDOUT, PH_STEAL, PH_DESCENT, PH_LEAF, PH_POOLMISC, PH_BSDF,
+       PH_ACCUM, PH_N_ROUNDS, PH_N_STEPS, PH_N_POOLS, PH_TAIL, PH_COUNT };
+
 struct LaneStats {
   uint32_t closest = 0, shadow = 0, knn = 0, nodes = 0, tris = 0, kd = 0;
   uint32_t wnode = 0, wleaf = 0;  // wave-level node steps / leaf phases (counted by the first active lane)
@@ -78,6 +97,27 @@ RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
 
 constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane holds no live ray"
 
+// Every LDS exchange in this file is between lanes of ONE wave (a wave owns its stack,
+// heap and pool regions), so no s_barrier is ever needed: a wave's DS operations are
+// executed in issue order, and this keeps the compiler from moving them across the
+// hand-over point.  (With one wave per workgroup __syncthreads() compiled to the same
+// thing; the persistent kernel runs 16 waves per workgroup, where it would not.)
+RT_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// byte offset of g_lds inside the workgroup's LDS segment (static __shared__ objects of
+// the diagnostic build come first)
+RT_DEV uint32_t ldsNodeBase();
+
+// Dynamic LDS of the render kernels.  The persistent pooled kernel keeps the TOP of the
+// BVH here — node records [0, topK), which bvh_build lays out most-visited first — in
+// front of the per-wave regions: one copy per CU, shared by all of its waves.
+extern __shared__ uint32_t g_lds[];
+RT_DEV uint32_t ldsNodeBase() { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)g_lds; }
+
 // One lane's ray in flight.  round() advances every lane of the wave that holds a
 // live ray by one "while-while" round: first the wave descends inner nodes until only a
 // few lanes are still descending (lanes that already hold a leaf sit out, masked; the
@@ -88,13 +128,23 @@ constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane holds no live ray"
 // below).
 constexpr int TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_MIXED = 2;  // MIXED: per-lane `anyHit` flag
 
-template <int MODE>
+// LT: where node records live.  LT_NONE: HBM/L2 through the vector L1; LT_TOP: records
+// [0, S.topK) in LDS (g_lds), the rest in HBM/L2; LT_ALL: the whole tree in LDS.
+constexpr int LT_NONE = 0, LT_TOP = 1, LT_ALL = 2;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
+
+template <int MODE, int LT = LT_NONE>
 struct Trav {
   f3 o, d, inv, oi;
   float best;
   uint32_t bestId;
   bool found, anyHit;
-  int sp;
+  // LDS stack of this lane: row 0 holds a TERM sentinel, entries live in rows 1..depth;
+  // `top` points at the top entry (or at the sentinel: an empty stack pops TERM by itself,
+  // so no step ever tests for emptiness or clamps an index)
+  uint32_t* top;
+  uint32_t* base;
   int32_t cur;
   HitRec hit;
   // pool mode (TRAV_MIXED): several lanes may walk disjoint subtrees of ONE ray
@@ -107,7 +157,8 @@ struct Trav {
   unsigned long long* sharedKey;
   uint32_t pj;
 
-  RT_DEV void idle() { cur = TERM, found = false, sp = 0, stolen = 0, shared = false; }
+  RT_DEV int depth() const { return (int)(top - base) / BLOCK; }  // entries on the stack (live lanes only)
+  RT_DEV void idle(uint32_t* stack) { cur = TERM, found = false, base = top = stack, stolen = 0, shared = false; }
   RT_DEV void start(f3 o_, f3 d_, float invScale) {
     o = o_, d = d_;
     const f3 i1 = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
@@ -115,7 +166,8 @@ struct Trav {
     // boxes are stored as coordinate * boxScale (a power of two): fold 1/boxScale in
     inv = mk(i1.x * invScale, i1.y * invScale, i1.z * invScale);
     best = 3.402823466e+38f;  // numeric_limits<float>::max(), RayTracer.h:30
-    bestId = 0, found = false, sp = 0, cur = 0, stolen = 0, shared = false;
+    bestId = 0, found = false, top = base, cur = 0, stolen = 0, shared = false;
+    *base = (uint32_t)TERM;
     // A ray with a NaN component cannot hit anything: Ray.cpp:9-24 then yields NaN u
     // or v for every triangle and every comparison fails (hemisphere samples are NaN
     // with p ~ 3e-8).  The slab test, built from min/max that drop
@@ -126,19 +178,33 @@ struct Trav {
   RT_DEV bool live() const { return cur != TERM; }
 
   template <bool STATS>
-  RT_DEV void round(const DevScene& S, uint32_t* stack, LaneStats& st) {
+  RT_DEV void round(const DevScene& S, LaneStats& st) {
     const int live0 = __popcll(__ballot(cur != TERM));
     const int exitBelow = min((int)S.leafT, (live0 + 2) / 3);
     uint32_t statWait = 0, statIdle = 0;
     if (STATS) statWait = (uint32_t)__popcll(__ballot(cur < 0 && cur != TERM)), statIdle = (uint32_t)__popcll(__ballot(cur == TERM));
+    PHC(PH_N_ROUNDS);
     while (cur >= 0) {
       // 32-B packed node: 12 x f16 planes + 2 refs (32-bit byte offset from a uniform base:
       // the load takes the base from SGPRs)
-      const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + ((uint32_t)cur << 5));
-      const uint4 a = n[0], b = n[1];
+      uint4 a, b;
+      if (LT == LT_ALL || (LT == LT_TOP && (uint32_t)cur < S.topK)) {
+        // from LDS (the tree copy starts at LDS byte offset 0 of the dynamic segment): a
+        // divergent 32-B read costs the LDS a few cycles per wave where the vector L1 spends
+        // one tag lookup per lane and dwordx4
+        uint32_t off = (uint32_t)cur << 5;
+        if (LT == LT_TOP) asm volatile("" : "+v"(off));  // keep the two address spaces on separate paths (else: one flat load)
+        lds_u4_ptr n = (lds_u4_ptr)(uintptr_t)(off + ldsNodeBase());
+        const u32x4 va = n[0], vb = n[1];
+        a = make_uint4(va.x, va.y, va.z, va.w), b = make_uint4(vb.x, vb.y, vb.z, vb.w);
+      } else {
+        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + ((uint32_t)cur << 5));
+        a = n[0], b = n[1];
+      }
+      PHC(PH_N_STEPS);
       // the entry a miss would pop, fetched with the node (its latency hides behind the
       // node's; a read in the divergent pop branch made every step wait for LDS)
-      const int32_t below = (int32_t)stack[max(sp - 1, 0) * BLOCK];
+      const int32_t below = (int32_t)*top;
       const int2 ch = make_int2((int)b.z, (int)b.w);
       if (STATS) {
         st.nodes++;
@@ -152,10 +218,9 @@ struct Trav {
       // both children were hit)
       const bool both = h0 && h1, any = h0 || h1;
       const bool takeY = h1 && (!h0 || t1 < t0);  // which child to enter (lane-mask logic, no selects)
-      stack[sp * BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
-      sp += both ? 1 : 0;
-      cur = takeY ? ch.y : ch.x;
-      if (!any) cur = sp > 0 ? below : TERM, sp = max(sp - 1, 0);
+      top[BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
+      cur = any ? (takeY ? ch.y : ch.x) : below;
+      top += both ? BLOCK : any ? 0 : -BLOCK;  // (a lane that pops the sentinel is dead until start())
       // leave the descent early once only a few lanes are still descending: they
       // sit out one leaf phase (masked) instead of making everyone else wait for them
       // (only when the lanes that would otherwise wait clearly outnumber them: in the
@@ -163,6 +228,7 @@ struct Trav {
       // (desc < leafT and 3 * desc < live0, folded into one threshold)
       if (__popcll(__ballot(cur >= 0)) < exitBelow) break;
     }
+    PH(PH_DESCENT);
     if (cur < 0 && cur != TERM) {
       const uint32_t code = ~(uint32_t)cur;
       const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
@@ -178,13 +244,10 @@ struct Trav {
         const float4* q = S.tris + 3 * (size_t)(first + i);
         stop = test_record<STATS>(q[0], q[1], q[2], st);
       }
-      if (stop || sp == 0) {
-        cur = TERM;
-      } else {
-        sp--;
-        cur = (int32_t)stack[sp * BLOCK];
-      }
+      cur = stop ? TERM : (int32_t)*top;
+      top -= BLOCK;
     }
+    PH(PH_LEAF);
   }
 
   // The first two records of a leaf at once and without a branch: both tests run, every
@@ -258,12 +321,16 @@ struct Trav {
 //   ANY = true : stops at the first accepted triangle with t > 0 (Renderer.cpp:54
 //                only uses the bool)
 // `on` = this lane has a ray; lanes without one still take part in the wave loop.
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, int LT = LT_NONE>
 RT_DEV bool traverse(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
-  Trav<ANY ? TRAV_ANY : TRAV_CLOSEST> T;
-  T.idle();
+  Trav<ANY ? TRAV_ANY : TRAV_CLOSEST, LT> T;
+  T.idle(stack);
   if (on) T.start(o, d, S.invBoxScale);
-  while (__ballot(T.live()) != 0) T.template round<STATS>(S, stack, st);
+  PH(PH_SETUP);
+  while (__ballot(T.live()) != 0) {
+    T.template round<STATS>(S, st);
+    PH(PH_PRIMARY);  // (round() itself books descent and leaf time; the primary cast is coherent)
+  }
   if (!ANY && T.found) hit = T.hit;
   return T.found;
 }
@@ -290,10 +357,10 @@ RT_DEV bool brute(const DevScene& S, f3 o, f3 d, HitRec& hit, LaneStats& st) {
 }
 
 // `on`: lanes without a ray pass false (wave-uniform call sites, no early exits).
-template <bool BRUTE, bool ANY, bool STATS>
+template <bool BRUTE, bool ANY, bool STATS, int LT = LT_NONE>
 RT_DEV bool cast(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
   if (BRUTE) return on && brute<ANY, STATS>(S, o, d, hit, st);
-  return traverse<ANY, STATS>(S, on, o, d, stack, hit, st);
+  return traverse<ANY, STATS, LT>(S, on, o, d, stack, hit, st);
 }
 
 // Renderer.cpp:274-277 dotArr: (w*a + u*b) + v*c per component
@@ -564,10 +631,10 @@ constexpr int VP_PT = 0, VP_DIR = 192, VP_BDIR = VP_DIR + 192 * POOL_L, VP_KEY =
 constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
 static_assert(VP_KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 
-template <bool STATS>
+template <bool STATS, int LT>
 RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
                       f3 point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
-  const uint32_t lane = threadIdx.x, nl = S.n_lights;
+  const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
   float* fp = reinterpret_cast<float*>(pool);
   // 32 words: rank -> pixel lane (64 bytes) while rays are handed out; then rank -> victim
   // word while stealing (min(victims, free lanes) <= 32 entries)
@@ -580,6 +647,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   f3 color = mk(0.f, 0.f, 0.f);
   nextFound = false;
   if (n == 0) return color;
+  PH(PH_VSETUP);
+  PHC(PH_N_POOLS);
   if (alive) {
     fp[VP_PT + lane] = point.x, fp[VP_PT + 64 + lane] = point.y, fp[VP_PT + 128 + lane] = point.z;
     // draw order of the reference: the light samples in light order (Renderer.cpp:52),
@@ -598,11 +667,12 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
     if (bounce) st.closest++;
   }
   if (lane < 2 * POOL_L) res[lane] = 0;
-  __syncthreads();
+  wave_sync();
+  PH(PH_FILL);
   const uint32_t kinds = nl + (bounce ? 1u : 0u), R = n * kinds;
   uint32_t head = 0, myK = 0, myJ = 0;
-  Trav<TRAV_MIXED> T;
-  T.idle();
+  Trav<TRAV_MIXED, LT> T;
+  T.idle(stack);
   T.sharedKey = keys, T.pj = 0;
   uint32_t* stackBase = stack - lane;
   for (;;) {
@@ -627,6 +697,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
         }
         head += (uint32_t)nIdle;
       }
+      PH(PH_HANDOUT);
     } else if (nIdle >= (int)S.stealT) {
       // The pool is empty and many workers are free: the tail.  A few long rays would
       // now keep 64 lanes waiting (measured: 75 % of the rounds ran with 8 live lanes).
@@ -643,7 +714,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       uint16_t* list16 = reinterpret_cast<uint16_t*>(list);
       uint32_t given = 0;
       for (int pass = 0; pass < 4; pass++) {
-        const bool canGive = T.live() && T.sp > T.stolen;
+        const bool canGive = T.live() && T.depth() > T.stolen;
         const uint64_t vmask = __ballot(canGive);
         if (vmask == 0 || given >= (uint32_t)nIdle) break;
         if (canGive) {
@@ -659,7 +730,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       }
       if (given != 0) {
         given = given < (uint32_t)nIdle ? given : (uint32_t)nIdle;
-        __syncthreads();
+        wave_sync();
         const uint32_t q = lanes_below(idle);
         const bool thief = !T.live() && q < given;
         const uint32_t w = thief ? (uint32_t)list16[q] : lane;
@@ -667,7 +738,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
         const uint32_t kj = (uint32_t)__shfl((int)(myK | (myJ << 8)), (int)v, 64);  // (all lanes take part)
         if (thief) {
           const uint32_t k = kj & 255u, j = kj >> 8;
-          uint32_t* slot = stackBase + e * BLOCK + v;
+          uint32_t* slot = stackBase + (e + 1u) * BLOCK + v;  // (row 0 is the sentinel)
           const int32_t node = (int32_t)*slot;
           *slot = (uint32_t)TERM;
           const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
@@ -678,8 +749,9 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
           T.anyHit = k < nl, T.pj = j, T.shared = true;
           myK = k, myJ = j;
         }
-        __syncthreads();
+        wave_sync();
       }
+      PH(PH_STEAL);
     }
     if (__ballot(T.live()) == 0) break;
     if (T.shared && T.live()) {
@@ -692,13 +764,16 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       }
     }
     const bool was = T.live();
-    T.template round<STATS>(S, stack, st);
+    PH(PH_POOLMISC);
+    if (head >= R) PHC(PH_TAIL);
+    T.template round<STATS>(S, st);
     if (was && !T.live() && T.found) {
       if (myK < nl) atomicOr(&res[myK * 2 + (myJ >> 5)], 1u << (myJ & 31));
       else if (!T.shared) T.publish();  // shared rays publish every improvement as it happens
     }
   }
-  __syncthreads();
+  wave_sync();
+  PH(PH_POOLMISC);
   if (alive) {
     const BsdfBase base = bsdf_base(S.mats[mesh], hitNormal, -rayDir);  // the light-independent half, once
     for (uint32_t l = 0; l < nl; l++) {
@@ -715,7 +790,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       next.u = next.v = 0.f, next.mesh = 0u;  // vertex_setup_ray works from the id
     }
   }
-  __syncthreads();  // the pool is rewritten by the next vertex
+  wave_sync();  // the pool is rewritten by the next vertex
+  PH(PH_BSDF);
   return color;
 }
 
@@ -750,8 +826,8 @@ RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool 
 template <bool PHOTON>
 RT_DEV Lds carve_lds(uint32_t* base, uint32_t levels = STACK, uint32_t kslots = KMAX) {
   Lds L;
-  L.stack = base + threadIdx.x;
-  L.heap = PHOTON ? reinterpret_cast<uint2*>(base + levels * BLOCK) + threadIdx.x : nullptr;
+  L.stack = base + (threadIdx.x & 63u);
+  L.heap = PHOTON ? reinterpret_cast<uint2*>(base + levels * BLOCK) + (threadIdx.x & 63u) : nullptr;
   return L;
 }
 
@@ -760,127 +836,174 @@ RT_DEV Lds carve_lds(uint32_t* base, uint32_t levels = STACK, uint32_t kslots = 
 // calculateColorPath (:106-201) with the recursion unrolled to a loop.  Control
 // flow is wave-uniform (per-lane `alive` flags instead of early exits) because the
 // direct-lighting step exchanges rays between lanes through LDS.
+// One wave tile: lane = (pixel pl of the tile, sample slot sj).  The wave integrates
+// S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side.
+template <bool BRUTE, bool PHOTON, bool POOLED, bool STATS, int LT>
+RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restrict__ accum, const Lds& L, uint32_t* pool,
+                        float* ex, uint32_t wave, LaneStats& st) {
+  const uint32_t lane = threadIdx.x & 63u;
+  // lane = (pixel pl of the wave tile, sample slot sj): the wave integrates
+  // S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side
+  const uint32_t tile = A.tiles[wave];
+  const uint32_t S_ = 1u << A.sshift, P_ = 64u >> A.sshift;
+  const uint32_t pl = lane & (P_ - 1u), sj = lane >> (6u - A.sshift);
+  const uint32_t wsh = (uint32_t)__builtin_ctz(A.tileW);
+  const uint32_t px = (tile & 0xffffu) + (pl & (A.tileW - 1u)), py = (tile >> 16) + (pl >> wsh);
+  const bool inImage = px < A.width && py < A.height;
+  const bool owner = inImage && sj == 0;  // adds this pixel's samples, in order
+  const uint32_t pix = inImage ? py * A.width + px : 0u;
+  float4 sum = owner ? accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr bool pooled = POOLED;  // chosen by the launcher: BVH, direct lighting, n_lights <= POOL_L
+  const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
+  for (uint32_t base = A.s0; base < A.s1; base += S_) {
+    const uint32_t i = base + sj;
+    const bool active = inImage && i < A.s1;
+    Rng g{rt_stream_seed(A.seed, RT_STREAM_PIXEL, pix, i)};
+    float sx, sy;
+    jitter_sample(g, (int)i, (int)A.spp, sx, sy);
+    f3 o, d;
+    camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
+    f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0;
+    bool primary = true, alive = active;
+    if constexpr (pooled) {
+      // primary ray (coherent: traced in lock step), then one pool per vertex
+      HitRec h;
+      if (alive) st.closest++;
+      const bool hit0 = cast<false, false, STATS, LT>(S, alive, o, d, L.stack, h, st);
+      if (alive && !hit0) primary = false, alive = false;
+      for (int depth = 0; depth < nvert; depth++) {
+        if (__ballot(alive) == 0) break;
+        const bool bounce = A.mode == RT_MODE_PATH && depth + 1 < nvert;  // wave-uniform
+        f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, bdir = nrm;
+        uint32_t mesh = 0;
+        if (alive) vertex_setup_ray(S, h.id, o, d, nrm, pt, mesh);
+        // (Renderer.cpp:164: the hemisphere sample is drawn after every shaded vertex;
+        // after the LAST one the reference draws it too but never traces it, and the
+        // stream ends there — the pool only draws it when a bounce ray follows)
+        HitRec nh;
+        bool nfound;
+        const f3 c = vertex_pool<STATS, LT>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
+        if (alive) {
+          if (depth == 0) c0 = c;
+          else if (depth == 1) c1 = c;
+          else c2 = c;
+          o = pt, d = bdir, h = nh;
+          if (!nfound) alive = false;
+        }
+      }
+    } else
+    for (int depth = 0; depth < nvert; depth++) {
+      HitRec h;
+      if (alive) st.closest++;
+      const bool hitv = cast<BRUTE, false, STATS>(S, alive, o, d, L.stack, h, st);
+      if (alive && !hitv) {
+        if (depth == 0) primary = false;
+        alive = false;
+      }
+      if (__ballot(alive) == 0) break;
+      f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, c = nrm;
+      if (alive) vertex_setup(S, h, nrm, pt);
+      if (PHOTON) {
+        if (alive) c = shade_photon<STATS>(S, A, d, h, L, nrm, pt, st);
+      } else {
+        if (alive) c = shade_direct_seq<BRUTE, STATS>(S, g, d, h, L.stack, nrm, pt, st);
+      }
+      if (alive) {
+        if (depth == 0) c0 = c;
+        else if (depth == 1) c1 = c;
+        else c2 = c;
+      }
+      if (A.mode != RT_MODE_PATH) break;
+      if (alive) {
+        d = hemisphere_sample(g, nrm);  // drawn after every shaded vertex (Renderer.cpp:164)
+        o = pt;
+      }
+    }
+    // calculateColorPath returns c0 + (c1 + (c2 + 0)) for finalDepth <= 3
+    PH(PH_VSETUP);
+    const f3 total = c0 + (c1 + (c2 + mk(0.f, 0.f, 0.f)));
+    const float r0 = clamp01(total.x), r1 = clamp01(total.y), r2 = clamp01(total.z);
+    if (A.sshift == 0) {
+      if (active) {
+        sum.x += r0, sum.y += r1, sum.z += r2;
+        if (primary) sum.w += 1.f;
+      }
+    } else {
+      // hand the sample to the pixel's owner lane, which adds samples base.. in order
+      // (Renderer.cpp:258: updateImage += colorResponse, i = 0..N-1)
+      ex[lane] = r0, ex[64 + lane] = r1, ex[128 + lane] = r2, ex[192 + lane] = primary ? 1.f : 0.f;
+      wave_sync();
+      if (owner) {
+        const uint32_t cnt = A.s1 - base < S_ ? A.s1 - base : S_;
+        for (uint32_t jj = 0; jj < cnt; jj++) {
+          const uint32_t q = jj * P_ + pl;
+          sum.x += ex[q], sum.y += ex[64 + q], sum.z += ex[128 + q];
+          sum.w += ex[192 + q];  // adds 1.0 or an exact 0.0
+        }
+      }
+      wave_sync();
+    }
+    PH(PH_ACCUM);
+  }
+  if (owner) accum[pix] = sum;
+}
+
 template <bool BRUTE, bool PHOTON, bool POOLED, bool STATS, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A, float4* __restrict__ accum,
                                                   unsigned long long* __restrict__ counters) {
-  static_assert(BLOCK == 64, "the shadow-ray pool assumes one wave per workgroup");
+  static_assert(BLOCK == 64, "one wave per workgroup");
   static_assert(!POOLED || (!BRUTE && !PHOTON), "the vertex pool serves BVH direct lighting");
   // dynamic LDS (render_lds_bytes): [levels][64] traversal stack, sized from the
   // depth of THIS scene's trees so that LDS does not cap occupancy; then the photon
   // k-heap or the shadow-ray pool
-  extern __shared__ uint32_t lds[];
+  uint32_t* lds = g_lds;
   const Lds L = carve_lds<PHOTON>(lds, A.stackLevels, A.k);
   uint32_t* pool = lds + (A.stackLevels + (PHOTON ? 2 * A.k : 0)) * BLOCK;
   // [4][64] sample results: share the pool's words, or (no pool) the first four stack
   // levels — both idle when a sample is handed over
   float* ex = reinterpret_cast<float*>(POOLED ? pool : lds);
-  const uint32_t wave = blockIdx.x;
-  const uint32_t lane = threadIdx.x;
   LaneStats st;
-  if (wave < A.n_tiles) {
-    // lane = (pixel pl of the wave tile, sample slot sj): the wave integrates
-    // S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side
-    const uint32_t tile = A.tiles[wave];
-    const uint32_t S_ = 1u << A.sshift, P_ = 64u >> A.sshift;
-    const uint32_t pl = lane & (P_ - 1u), sj = lane >> (6u - A.sshift);
-    const uint32_t wsh = (uint32_t)__builtin_ctz(A.tileW);
-    const uint32_t px = (tile & 0xffffu) + (pl & (A.tileW - 1u)), py = (tile >> 16) + (pl >> wsh);
-    const bool inImage = px < A.width && py < A.height;
-    const bool owner = inImage && sj == 0;  // adds this pixel's samples, in order
-    const uint32_t pix = inImage ? py * A.width + px : 0u;
-    float4 sum = owner ? accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr bool pooled = POOLED;  // chosen by the launcher: BVH, direct lighting, n_lights <= POOL_L
-    const int nvert = A.mode == RT_MODE_PATH ? (int)A.max_depth : 1;
-    for (uint32_t base = A.s0; base < A.s1; base += S_) {
-      const uint32_t i = base + sj;
-      const bool active = inImage && i < A.s1;
-      Rng g{rt_stream_seed(A.seed, RT_STREAM_PIXEL, pix, i)};
-      float sx, sy;
-      jitter_sample(g, (int)i, (int)A.spp, sx, sy);
-      f3 o, d;
-      camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
-      f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0;
-      bool primary = true, alive = active;
-      if constexpr (pooled) {
-        // primary ray (coherent: traced in lock step), then one pool per vertex
-        HitRec h;
-        if (alive) st.closest++;
-        const bool hit0 = cast<false, false, STATS>(S, alive, o, d, L.stack, h, st);
-        if (alive && !hit0) primary = false, alive = false;
-        for (int depth = 0; depth < nvert; depth++) {
-          if (__ballot(alive) == 0) break;
-          const bool bounce = A.mode == RT_MODE_PATH && depth + 1 < nvert;  // wave-uniform
-          f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, bdir = nrm;
-          uint32_t mesh = 0;
-          if (alive) vertex_setup_ray(S, h.id, o, d, nrm, pt, mesh);
-          // (Renderer.cpp:164: the hemisphere sample is drawn after every shaded vertex;
-          // after the LAST one the reference draws it too but never traces it, and the
-          // stream ends there — the pool only draws it when a bounce ray follows)
-          HitRec nh;
-          bool nfound;
-          const f3 c = vertex_pool<STATS>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
-          if (alive) {
-            if (depth == 0) c0 = c;
-            else if (depth == 1) c1 = c;
-            else c2 = c;
-            o = pt, d = bdir, h = nh;
-            if (!nfound) alive = false;
-          }
-        }
-      } else
-      for (int depth = 0; depth < nvert; depth++) {
-        HitRec h;
-        if (alive) st.closest++;
-        const bool hitv = cast<BRUTE, false, STATS>(S, alive, o, d, L.stack, h, st);
-        if (alive && !hitv) {
-          if (depth == 0) primary = false;
-          alive = false;
-        }
-        if (__ballot(alive) == 0) break;
-        f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, c = nrm;
-        if (alive) vertex_setup(S, h, nrm, pt);
-        if (PHOTON) {
-          if (alive) c = shade_photon<STATS>(S, A, d, h, L, nrm, pt, st);
-        } else {
-          if (alive) c = shade_direct_seq<BRUTE, STATS>(S, g, d, h, L.stack, nrm, pt, st);
-        }
-        if (alive) {
-          if (depth == 0) c0 = c;
-          else if (depth == 1) c1 = c;
-          else c2 = c;
-        }
-        if (A.mode != RT_MODE_PATH) break;
-        if (alive) {
-          d = hemisphere_sample(g, nrm);  // drawn after every shaded vertex (Renderer.cpp:164)
-          o = pt;
-        }
-      }
-      // calculateColorPath returns c0 + (c1 + (c2 + 0)) for finalDepth <= 3
-      const f3 total = c0 + (c1 + (c2 + mk(0.f, 0.f, 0.f)));
-      const float r0 = clamp01(total.x), r1 = clamp01(total.y), r2 = clamp01(total.z);
-      if (A.sshift == 0) {
-        if (active) {
-          sum.x += r0, sum.y += r1, sum.z += r2;
-          if (primary) sum.w += 1.f;
-        }
-      } else {
-        // hand the sample to the pixel's owner lane, which adds samples base.. in order
-        // (Renderer.cpp:258: updateImage += colorResponse, i = 0..N-1)
-        ex[lane] = r0, ex[64 + lane] = r1, ex[128 + lane] = r2, ex[192 + lane] = primary ? 1.f : 0.f;
-        __syncthreads();
-        if (owner) {
-          const uint32_t cnt = A.s1 - base < S_ ? A.s1 - base : S_;
-          for (uint32_t jj = 0; jj < cnt; jj++) {
-            const uint32_t q = jj * P_ + pl;
-            sum.x += ex[q], sum.y += ex[64 + q], sum.z += ex[128 + q];
-            sum.w += ex[192 + q];  // adds 1.0 or an exact 0.0
-          }
-        }
-        __syncthreads();
-      }
-    }
-    if (owner) accum[pix] = sum;
+  if (blockIdx.x < A.n_tiles) render_tile<BRUTE, PHOTON, POOLED, STATS, LT_NONE>(S, A, accum, L, pool, ex, blockIdx.x, st);
+  flush_stats(st, counters, STATS);
+}
+
+// The pooled integrator as PERSISTENT workgroups: one workgroup of up to 16 waves per CU
+// for the whole launch.  Its LDS holds ONE copy of the top of the BVH (node records
+// [0, topK), breadth-first) in front of the waves' private regions (traversal stack +
+// vertex pool), and every wave draws wave tiles from a global counter until none is
+// left — so a CU never idles behind a slow neighbour wave, and the node fetches of the
+// upper tree levels (all of them for the 1.2k-triangle scene) never touch the vector L1.
+// Waves never synchronise with each other after the tree copy.
+template <bool STATS, int LT>
+__global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs A, float4* __restrict__ accum,
+                                                         unsigned long long* __restrict__ counters) {
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  {
+    uint4* dst = reinterpret_cast<uint4*>(g_lds);
+    for (uint32_t i = threadIdx.x; i < 2u * S.topK; i += blockDim.x) dst[i] = S.nodes[i];
   }
+  __syncthreads();  // the only workgroup-wide barrier
+  uint32_t* mine = g_lds + 8u * S.topK + wv * A.waveWords;
+  const Lds L = carve_lds<false>(mine, A.stackLevels, 0);
+  uint32_t* pool = mine + A.stackLevels * BLOCK;
+  float* ex = reinterpret_cast<float*>(pool);
+  LaneStats st;
+#ifdef RT_PHASE_TIMING
+  if (threadIdx.x < 24) g_phAcc[threadIdx.x] = 0;
+  if (threadIdx.x == 0) g_phT0 = __builtin_amdgcn_s_memtime();
+  __syncthreads();
+#endif
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(A.tileCounter, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= A.n_tiles) break;
+    render_tile<false, false, true, STATS, LT>(S, A, accum, L, pool, ex, t, st);
+  }
+#ifdef RT_PHASE_TIMING
+  __syncthreads();
+  if (threadIdx.x < PH_COUNT) atomicAdd(&counters[16 + threadIdx.x], g_phAcc[threadIdx.x]);
+#endif
   flush_stats(st, counters, STATS);
 }
 
@@ -900,7 +1023,7 @@ __global__ void k_resolve(uint32_t n_pixels, float spp, const float4* __restrict
 template <bool BRUTE, bool ANY>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, const rt_ray* __restrict__ rays, uint32_t n,
                                                  rt_hit* __restrict__ hits, unsigned long long* counters) {
-  __shared__ uint32_t lds[STACK * BLOCK];
+  __shared__ uint32_t lds[(STACK + 1) * BLOCK];
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   LaneStats st;
   if (i < n) {
@@ -954,7 +1077,7 @@ template <bool BRUTE>
 __global__ __launch_bounds__(BLOCK) void k_emit(DevScene S, uint32_t perLight, uint32_t seed,
                                                 float4* __restrict__ outPos, float4* __restrict__ outDir,
                                                 unsigned long long* counters) {
-  __shared__ uint32_t lds[STACK * BLOCK];
+  __shared__ uint32_t lds[(STACK + 1) * BLOCK];
   uint32_t* stack = lds + threadIdx.x;
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   LaneStats st;
@@ -1101,23 +1224,79 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
 }
 
 // ---------------------------------------------------------------- launchers
+// LDS plan of the persistent pooled kernel: W waves per workgroup (one workgroup per CU),
+// topK tree-top nodes in front of W private regions of waveWords each.  160 KiB per CU.
+struct PersistPlan {
+  uint32_t waves, topK, waveWords, ldsBytes;
+};
+static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
+  const uint32_t total = 160u * 1024u / 4u - 64u;  // words (a little room for the diagnostic build's statics)
+  const uint32_t waveWords = A.stackLevels * BLOCK + VP_WORDS;
+  static const int wEnv = getenv("RT_PERSIST_WAVES") ? atoi(getenv("RT_PERSIST_WAVES")) : 0;
+  static const int kEnv = getenv("RT_TOPK") ? atoi(getenv("RT_TOPK")) : -1;
+  const uint32_t cap = S.n_nodes < rtbvh::kTopNodes ? S.n_nodes : rtbvh::kTopNodes;
+  // Measured (MI355X, Grays/s): occupancy comes first — 12 instead of 16 waves costs 15-17 %
+  // on every scene — and a PARTIAL top (LT_TOP: a branch per node step) gave C4 -2 %, while
+  // the whole tree in LDS (LT_ALL, no branch) gives C2 +5.6 %.  So: 16 waves; the tree goes
+  // to LDS only if all of it fits beside them.  RT_PERSIST_WAVES / RT_TOPK override.
+  PersistPlan best{0, 0, waveWords, 0};
+  uint32_t w = wEnv > 0 ? (uint32_t)wEnv : 16u;
+  while (w > 1u && w * waveWords > total) --w;
+  if (w * waveWords > total) return best;
+  uint32_t k = (total - w * waveWords) / 8u;
+  k = k < cap ? k : cap;
+  if (kEnv >= 0) k = (uint32_t)kEnv < k ? (uint32_t)kEnv : k;
+  else if (k < S.n_nodes) k = 0;
+  best = PersistPlan{w, k, waveWords, 4u * (8u * k + w * waveWords)};
+  return best;
+}
+
 template <bool BRUTE, bool PHOTON, bool POOLED>
 static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs& A, float4* accum,
                                  unsigned long long* counters, hipStream_t stream) {
   const uint32_t blocks = A.n_tiles;
+  if (blocks == 0) return hipSuccess;
+  static const bool noPersist = getenv("RT_NO_PERSIST") != nullptr;
+  if (POOLED && !noPersist && A.tileCounter && A.numCUs) {
+    const PersistPlan P = plan_persist(S, A);
+    if (P.waves) {
+      DevScene S2 = S;
+      RenderArgs A2 = A;
+      S2.topK = P.topK, A2.waveWords = P.waveWords;
+      hipError_t e = hipMemsetAsync(A.tileCounter, 0, sizeof(uint32_t), stream);
+      if (e != hipSuccess) return e;
+      const uint32_t perCU = P.waves;                                    // waves one workgroup brings
+      const uint32_t wgs = (blocks + perCU - 1) / perCU < A.numCUs ? (blocks + perCU - 1) / perCU : A.numCUs;
+      // dynamic LDS beyond 64 KiB must be allowed per kernel
+#define RT_LAUNCH_PERSIST(ST, LTV)                                                                                      \
+  do {                                                                                                                  \
+    static bool once = false;                                                                                           \
+    if (!once)                                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_persist<ST, LTV>),                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),                                \
+          once = true;                                                                                                  \
+    hipLaunchKernelGGL((k_render_persist<ST, LTV>), dim3(wgs), dim3(64u * P.waves), P.ldsBytes, stream, S2, A2, accum,  \
+                       counters);                                                                                       \
+  } while (0)
+      const int lt = P.topK == 0 ? LT_NONE : P.topK >= S.n_nodes ? LT_ALL : LT_TOP;
+      if (stats) {
+        if (lt == LT_ALL) RT_LAUNCH_PERSIST(true, LT_ALL);
+        else if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP);
+        else RT_LAUNCH_PERSIST(true, LT_NONE);
+      } else {
+        if (lt == LT_ALL) RT_LAUNCH_PERSIST(false, LT_ALL);
+        else if (lt == LT_TOP) RT_LAUNCH_PERSIST(false, LT_TOP);
+        else RT_LAUNCH_PERSIST(false, LT_NONE);
+      }
+#undef RT_LAUNCH_PERSIST
+      return hipGetLastError();
+    }
+  }
   const uint32_t rows = A.stackLevels + (PHOTON ? 2 * A.k : 0);
   const size_t ldsBytes = 4u * ((rows < 4u ? 4u : rows) * BLOCK + (POOLED ? VP_WORDS : 0));
-  if (blocks == 0) return hipSuccess;
-  // Occupancy target (waves per SIMD).  The pooled kernel exists as a 128-VGPR (4 waves)
-  // and a 96-VGPR (5 waves, some spills) build; the fifth wave only exists if the wave's
-  // LDS (stack levels + pool) leaves room for more than 16 waves per CU.  Measured:
-  // C2 (7.8 KB) 20.0 -> 20.6 Grays/s and C4 (8.6 KB) 17.8 -> 18.4 with 5; C5 (10.1 KB,
-  // 16 waves at most) 5.43 -> 5.33, so it stays at 4.  6 and 8 lose 5-15 %.
+  // Occupancy target (waves per SIMD) of the one-wave-per-workgroup kernels.
   constexpr int MINW = PHOTON ? 2 : 4;
-  static const int minwEnv = getenv("RT_MINWAVES") ? atoi(getenv("RT_MINWAVES")) : 0;
-  const int minw = minwEnv ? minwEnv : (POOLED && ldsBytes * 17 <= 160u * 1024u ? 5 : MINW);
   if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
-  else if (POOLED && minw == 5) hipLaunchKernelGGL((k_render<false, false, POOLED, false, 5>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
   return hipGetLastError();
 }

@@ -110,7 +110,8 @@ def amd():
     """librt_amd.so (HIP kernels + C ABI).  Loads without a GPU; compute calls then fail."""
     global _amd
     if _amd is None:
-        path = os.path.join(LIB_DIR, "librt_amd.so")
+        # RT_AMD_LIB: load a diagnostic build of the same library instead (tools/phase_timing.sh)
+        path = os.environ.get("RT_AMD_LIB") or os.path.join(LIB_DIR, "librt_amd.so")
         if not os.path.exists(path):
             raise RtError(-1, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)
