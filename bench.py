@@ -1,19 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X path-tracing hot path.
 
-Workload (BASELINE.json configs[1]): 1024x1024, -m 1 (path), -N 128 spp, Cornell
+Default workload (BASELINE.json configs[1]): 1024x1024, -m 1 (path), -N 128 spp, Cornell
 box with meshes/example_low_res.off in slot 3 (1,222 triangles), pixel-RNG seed 1.
 A "step" is one whole frame: zero the accumulator, integrate every sample of every
-owned pixel (one HIP launch per rank), reduce over ranks (N>1), resolve on rank 0.
-Metric: Mrays/s = (closest-hit + shadow rays actually cast) / wall time, whole job.
+owned pixel (one HIP launch per rank), assemble the frame over ranks (N>1), resolve on
+rank 0.  Metric: Mrays/s = (closest-hit + shadow rays actually cast) / wall time, whole job.
 
   python bench.py --gpus N --steps K --warmup W
-N>1 is launched by torch.distributed.run, one rank per GPU (RCCL); the frame is
-tile-sharded over ranks, i.e. total work is fixed: "scaling": "strong".
+With N>1 and no WORLD_SIZE in the environment the script starts its own
+`torch.distributed.run` (one rank per GPU, RCCL) as a child process, before anything
+touches the GPU.  The frame is tile-sharded over ranks, i.e. total work is fixed:
+"scaling": "strong".
+
+The JSON line carries
+  roofline      the roof that BINDS the dominant kernel: VALU issue rate for the cache-
+                resident scenes (C1-C4; SQ_INSTS_VALU of the timed kernel / its time against
+                1024 SIMDs x 2.4 GHz / 2 cycles per wave64 op), HBM bytes for the 1M-triangle
+                scene (C5).  Counters are measured IN THIS RUN by rocprofv3 child passes
+                (N=1 only; --no-pmc skips them and falls back to profiles/, marked as such).
+  cpu_baseline  the reference's own code timed on the host beside it, plus the CPU
+                restatement with and without a BVH and the GPU exhaustive kernel, so that
+                the hardware gain and the algorithmic gain can be read separately.
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -23,7 +39,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracing-engine_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 256 * 4           # 256 CUs x 4 SIMD-32
+CLOCK_GHZ = 2.4           # max shader clock (same guide)
+VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / 2.0  # one wave64 VALU op per 2 cycles per SIMD -> 1228.8 G wave-instr/s
 
 WORKLOADS = {
     # name: (scene, width, height, spp, mode, photons, k)
@@ -32,20 +51,108 @@ WORKLOADS = {
     "C3": ("cubes", 1024, 1024, 16, 0, 50000, 10),
     "C4": ("hires", 2048, 2048, 512, 1, 0, 0),
     "C5": ("stress", 1024, 1024, 256, 1, 0, 0),
+    # supplementary: 8x the C5 lattice (8M triangles, ~0.9 GB of nodes + triangle records: beyond
+    # the 256 MB Infinity Cache, so FETCH_SIZE is HBM traffic proper)
+    "C5x8": ("stress8", 1024, 1024, 32, 1, 0, 0),
 }
+HBM_BOUND = ("C5", "C5x8")
 
 
-def cpu_baseline(scene_kind, mode, spp_full):
-    """The REAL reference (oracle/_ref/ref_harness = reference sources + our driver)
-    timed single-threaded on a bounded sample of the same workload: same scene, same
-    mode, 8 spp at 96x96 (~74k samples, ~10 s; brute force costs ~0.13 ms per sample on
-    the low-res scene).  Rays are counted by the oracle's legacy mode on the same input
-    (its image is byte-identical to the reference's, so the counts are the reference's)."""
+def kernel_source_hash():
+    """Identity of the device code the counters belong to (profiles/*.json carry it)."""
+    h = hashlib.sha1()
+    for rel in ("ray-tracing-engine_amd/csrc/rt_kernels.hip", "ray-tracing-engine_amd/csrc/rt_device.h",
+                "ray-tracing-engine_amd/csrc/rt_kernels.h", "include/rt_pixelmode.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def metric_text(wl):
+    kind, w, h, spp, mode, nph, k = WORKLOADS[wl]
+    what = "path trace" if mode == 1 else "ray trace"
+    if nph:
+        what += " + photon map"
+    return "Mrays/s (primary+secondary) at %dx%d/%dspp %s" % (w, h, spp, what)
+
+
+# ----------------------------------------------------------------------------- PMC passes
+PMC_PASSES = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVES",
+               "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
+              ["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE"]]
+
+
+def is_timed_render_kernel(name):
+    """The integrate kernel of the TIMED launches (not the one STATS pass)."""
+    if "k_render_persist<" in name:
+        return name.split("k_render_persist<")[1].split(">")[0].split(",")[0].strip() in ("false", "0")
+    if "k_render<" in name:
+        return name.split("k_render<")[1].split(">")[0].split(",")[3].strip() in ("false", "0")
+    return False
+
+
+def pmc_measure(args):
+    """rocprofv3 --pmc child passes over ONE frame of the same workload (program after `--`
+    is python3 itself; --kernel-trace only).  Returns {counter: value per launch} or None."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out = {}
+    base = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, group in enumerate(PMC_PASSES):
+            d = os.path.join(base, "p%d" % i)
+            cmd = [rocprof, "--kernel-trace", "--pmc"] + group + ["--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--accel", args.accel]
+            if args.spp:
+                cmd += ["--spp", str(args.spp)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            rows = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if is_timed_render_kernel(row["Kernel_Name"]):
+                        rows.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if not rows:
+                return None, "pass %d produced no counters (rc %d): %s" % (i, r.returncode, (r.stderr or r.stdout)[-300:])
+            for c, v in rows.items():
+                out[c] = sum(v) / len(v)
+    except Exception as e:  # the counters must never cost the bench line
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return out, "rocprofv3 --pmc child passes of this run (1 frame each)"
+
+
+def pmc_child(args):
+    """One untimed frame of the workload: what the rocprofv3 passes wrap."""
+    import torch
+    import pyrt
+    kind, w, h, spp, mode, nph, k = WORKLOADS[args.workload]
+    spp = args.spp or spp
+    scene = pyrt.Scene(kind, w, h)
+    ctx = pyrt.Context(scene, device=0)
+    params = build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, 0, 1)
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    ctx.render_device(params, accum.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ctx.close()
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(ctx, scene_kind, mode, device):
+    """The REAL reference (oracle/_ref/ref_harness = reference sources + our driver), timed
+    single-threaded on a bounded sample of the same scene and mode (96x96, 8 spp, ~10 s:
+    brute force costs ~0.13 ms per sample on the low-res scene; BASELINE config 1 is the same
+    command at 256x256 — 7x the samples, same rate).  Beside it, for the decomposition of the
+    GPU/CPU ratio: the CPU restatement (oracle) single-threaded with the exhaustive loop and
+    with its own BVH on config 1's full 256x256x8, both again on all host cores, and the GPU's
+    exhaustive kernel.  hardware gain = like for like (loop/loop, BVH/BVH); the rest is the
+    algorithm."""
+    import numpy as np
     import orc
     import pyrt
     w = h = 96
     n = 8
-    meshes = pyrt.MESH_DIR
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     scene = pyrt.Scene(scene_kind, w, h)
     p = pyrt.make_params(w, h, n, mode=mode, rng_mode=pyrt.RNG_LEGACY)
@@ -53,42 +160,97 @@ def cpu_baseline(scene_kind, mode, spp_full):
     _, _, st = orc.render(scene, p, math_mode=orc.MATH_LIBM)
     t_port = time.perf_counter() - t0
     rays = st.rays_closest + st.rays_shadow
-    # the same sample on ALL host cores: the CPU restatement in pixel-RNG mode (independent
-    # pixels, OpenMP), brute force like the reference.  (The reference itself cannot run
-    # multi-threaded: one global RNG.)
+    out = {"unit": "Mrays/s", "cores": 1,
+           "sample": "%s scene, %dx%d, -m %d -N %d, legacy RNG seed 1 (%d rays; BASELINE config 1 is this command at "
+                     "256x256: same rate, 7x the work)" % (scene_kind, w, h, mode, n, rays),
+           "port_loop_value": rays / t_port / 1e6}
+    # the restatement through its CPU BVH, single thread, on config 1's full size
+    big = pyrt.Scene(scene_kind, 256, 256)
+    pb = pyrt.make_params(256, 256, 8, mode=mode, rng_mode=pyrt.RNG_LEGACY)
+    t0 = time.perf_counter()
+    _, _, sb = orc.render(big, pb, math_mode=orc.MATH_LIBM, accel=orc.ACCEL_OBVH)
+    t_bvh = time.perf_counter() - t0
+    out["port_bvh_value"] = (sb.rays_closest + sb.rays_shadow) / t_bvh / 1e6
+    out["port_bvh_sample"] = "%s scene, 256x256, -m %d -N 8 (BASELINE config 1's size), oracle CPU BVH, 1 thread" % (scene_kind, mode)
+    # all host cores (pixel RNG mode: independent pixels, OpenMP; the reference itself cannot
+    # run multi-threaded: one global RNG)
+    threads = len(os.sched_getaffinity(0))
     pp = pyrt.make_params(w, h, n, mode=mode, rng_mode=pyrt.RNG_PIXEL)
     t0 = time.perf_counter()
-    _, _, stp = orc.render(scene, pp, math_mode=orc.MATH_DET, threads=0)
-    t_all = time.perf_counter() - t0
-    all_cores = {"port_all_cores_value": (stp.rays_closest + stp.rays_shadow) / t_all / 1e6,
-                 "port_all_cores_threads": len(os.sched_getaffinity(0))}
-    sample = "%s scene, %dx%d, -m %d -N %d, legacy RNG seed 1 (%d rays)" % (scene_kind, w, h, mode, n, rays)
+    _, _, s1 = orc.render(scene, pp, math_mode=orc.MATH_DET, threads=0)
+    out["port_loop_all_cores_value"] = (s1.rays_closest + s1.rays_shadow) / (time.perf_counter() - t0) / 1e6
+    pq = pyrt.make_params(512, 512, 16, mode=mode, rng_mode=pyrt.RNG_PIXEL)
+    s512 = pyrt.Scene(scene_kind, 512, 512)
+    t0 = time.perf_counter()
+    _, _, s2 = orc.render(s512, pq, math_mode=orc.MATH_DET, threads=0, accel=orc.ACCEL_OBVH)
+    out["port_bvh_all_cores_value"] = (s2.rays_closest + s2.rays_shadow) / (time.perf_counter() - t0) / 1e6
+    out["all_cores_threads"] = threads
+    # the GPU's exhaustive kernel (the reference algorithm itself on the GPU), bounded frame
+    try:
+        gp = pyrt.make_params(512, 512, 8, mode=mode, seed=1, accel=pyrt.ACCEL_BRUTE)
+        ctx.render(gp, want_accum=False)
+        _, _, sg = ctx.render(gp, want_accum=False)
+        out["gpu_loop_value"] = (sg.rays_closest + sg.rays_shadow) / (sg.kernel_ms * 1e-3) / 1e6
+        out["gpu_loop_sample"] = "same scene, 512x512, 8 spp, --accel brute (kernel time)"
+    except Exception as e:
+        out["gpu_loop_value"] = None
+        out["gpu_loop_sample"] = "failed: %s" % e
     if os.path.exists(harness):
         try:
             with tempfile.TemporaryDirectory() as tmp:
-                r = subprocess.run([harness, "time", meshes, scene_kind, str(w), str(h), str(mode), str(n), "0", "0"],
+                r = subprocess.run([harness, "time", pyrt.MESH_DIR, scene_kind, str(w), str(h), str(mode), str(n), "0", "0"],
                                    cwd=tmp, capture_output=True, text=True, check=True, timeout=300)
             secs = json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
-            return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference", "sample": sample,
-                    "seconds": secs, "port_value": rays / t_port / 1e6, **all_cores}
+            out.update({"value": rays / secs / 1e6, "kind": "reference", "seconds": secs})
+            return out
         except Exception as e:  # the baseline must never cost the bench line: fall back to the port
-            sample += " [reference harness failed: %s]" % type(e).__name__
-    return {"value": rays / t_port / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample,
-            "seconds": t_port, **all_cores}
+            out["sample"] += " [reference harness failed: %s]" % type(e).__name__
+    out.update({"value": rays / t_port / 1e6, "kind": "port", "seconds": t_port})
+    return out
+
+
+def build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, rank, world):
+    accel = pyrt.ACCEL_BRUTE if args.accel == "brute" else pyrt.ACCEL_BVH
+    if nph:
+        pos, dr, wt = ctx.emit_photons(nph, seed=1)
+        kp, kd_, _ = pyrt.kd_order(pos, dr, wt)
+        ctx.set_photons(kp, kd_)
+    return pyrt.make_params(w, h, spp, mode=mode, seed=1, accel=accel, rank=rank, world=world, tile=32,
+                            use_photons=1 if nph else 0, k=k, photons_requested=nph, lanes_per_pixel=args.lpp)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--accel", default="bvh", choices=["bvh", "brute"])
     ap.add_argument("--leaf", type=int, default=0, help="BVH leaf size override (debug)")
     ap.add_argument("--lpp", type=int, default=0, help="samples of a pixel per wave override (debug)")
     args = ap.parse_args()
+
+    if args.pmc_child:
+        return pmc_child(args)
+
+    # N > 1 without a launcher: become the launcher (a CHILD process, before any GPU call)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    rank_env = int(os.environ.get("RANK", "0"))
+    # counters of the timed kernel, measured now, by child processes, before this process
+    # initialises the GPU (N = 1 only: the counters describe one GPU's launch)
+    pmc, pmc_source = None, "skipped (--no-pmc)" if args.no_pmc else "not measured at N > 1"
+    if world_env == 1 and not args.no_pmc:
+        pmc, pmc_source = pmc_measure(args)
 
     import torch
     import pyrt
@@ -100,7 +262,7 @@ def main():
     if os.environ.get("RT_SHARE_GPU") == "1":
         local = 0
     if world != args.gpus:
-        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d (launch with torch.distributed.run)" % (world, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -109,24 +271,18 @@ def main():
         spp = args.spp
     scene = pyrt.Scene(kind, w, h)
     ctx = pyrt.Context(scene, device=local, bvh_leaf_max=args.leaf)  # raises if the HIP library / a gfx950 device is missing
-    accel = pyrt.ACCEL_BRUTE if args.accel == "brute" else pyrt.ACCEL_BVH
-    use_ph = 1 if nph else 0
-    if nph:
-        pos, dr, wt = ctx.emit_photons(nph, seed=1)
-        kp, kd_, _ = pyrt.kd_order(pos, dr, wt)
-        ctx.set_photons(kp, kd_)
-    params = pyrt.make_params(w, h, spp, mode=mode, seed=1, accel=accel, rank=rank, world=world, tile=32,
-                              use_photons=use_ph, k=k, photons_requested=nph, lanes_per_pixel=args.lpp)
+    params = build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, rank, world)
 
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
     bg = torch.from_numpy(pyrt.background(w, h)).to(dev)
     out = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    frame = rdist.FrameAssembler(ctx, params, rank, world, dev)  # owned tiles -> rank 0 (one gather)
 
     def step():
         accum.zero_()
         ctx.render_device(params, accum.data_ptr(), stream)
-        rdist.reduce_frame(accum, dst=0)
+        frame.assemble(accum, stream)
         if rank == 0:
             ctx.resolve_device(w, h, spp, accum.data_ptr(), bg.data_ptr(), out.data_ptr(), stream)
 
@@ -154,26 +310,73 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = rdist.max_over_ranks(elapsed, dev)
     kernel_ms, launches = ctx.profile_collect()
-
-    # roofline of the dominant kernel (k_render) on THIS rank: algorithmic bytes per
-    # launch = bytes per unit x units of this launch: one BVH node record
-    # per node fetched (32 B: the packed f16 node this build traverses; §8d priced a
-    # 64-B float node), 48 B per triangle record tested, 16 B per pixel-sample for the
-    # accumulator, 32 B (position + direction) per kd node visited
-    alg_bytes = 32 * local_counts[2] + 48 * local_counts[3] + 16 * local_counts[4] + 32 * local_counts[6]
     avg_ms = kernel_ms / max(launches, 1)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    secs = avg_ms * 1e-3
 
-    # HBM traffic of the same launch from PMC counters (tools/traffic.sh, committed under
-    # profiles/): FETCH_SIZE (doubled, gfx950 correction) + WRITE_SIZE
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.workload)
-    if os.path.exists(tpath) and not args.spp and world == 1 and args.accel == "bvh":
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    # ALGORITHMIC bytes per launch (SURVEY §8d per-unit figures x the units of this launch): 32 B
+    # per node record fetched (the packed node this build traverses; §8d priced a 64-B float
+    # node), 48 B per triangle record tested, 16 B per pixel-sample (accumulator), 32 B per kd node
+    alg_bytes = 32 * local_counts[2] + 48 * local_counts[3] + 16 * local_counts[4] + 32 * local_counts[6]
+    scene_mb = (32 * ctx.bvh_info().n_nodes + 48 * scene.desc.n_triangles) / 1e6
+
+    # counters: this run's, or (fallback) a committed profile of the SAME device code
+    khash = kernel_source_hash()
+    if pmc is None:
+        ppath = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.workload)
+        if os.path.exists(ppath) and not args.spp and world == 1 and args.accel == "bvh":
+            saved = json.load(open(ppath))
+            if saved.get("kernel_source_hash") == khash:
+                pmc, pmc_source = saved["counters"], "profiles/r02_pmc_%s.json @ kernel hash %s [%s]" % (args.workload, khash, pmc_source)
+            else:
+                pmc_source = "profiles/r02_pmc_%s.json is for kernel hash %s, this build is %s: not used [%s]" % (
+                    args.workload, saved.get("kernel_source_hash"), khash, pmc_source)
+    hbm_bytes = valu = lane_util = None
+    if pmc:
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # rocprofv3 reports KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B: guide, HBM section)
+            hbm_bytes = 2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024
+        valu = pmc.get("SQ_INSTS_VALU")
+        if valu and pmc.get("SQ_THREAD_CYCLES_VALU"):
+            # active lanes per VALU wave-instruction / 64
+            lane_util = min(pmc["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 1.0)
 
     if rank == 0:
+        hbm_roof = {"bound": "hbm", "achieved": (hbm_bytes / secs / 1e9) if hbm_bytes and secs > 0 else None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        hbm_roof["frac"] = hbm_roof["achieved"] / HBM_PEAK_GBS if hbm_roof["achieved"] is not None else None
+        valu_roof = {"bound": "valu_issue", "achieved": (valu / secs / 1e9) if valu and secs > 0 else None,
+                     "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s"}
+        valu_roof["frac"] = valu_roof["achieved"] / VALU_PEAK_GINSTR if valu_roof["achieved"] is not None else None
+        primary = hbm_roof if args.workload in HBM_BOUND else valu_roof
+        roof = dict(primary)
+        roof.update({
+            "traffic": hbm_bytes,  # measured HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)
+            "traffic_source": pmc_source, "kernel_source_hash": khash,
+            "kernel": "k_render_persist" if args.accel == "bvh" and not nph else "k_render",
+            "kernel_ms_avg": avg_ms, "launches": launches,
+            "valu_issue": valu_roof, "hbm": hbm_roof,
+            "valu_lane_utilisation": lane_util,
+            # what the caches served: SURVEY §8d's per-unit bytes x units; NOT an HBM fraction (the scene is
+            # %.2f MB) — priced against HBM peak it may exceed 1, which only says the caches work
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_gbs": alg_bytes / secs / 1e9 if secs > 0 else None,
+            "scene_mb": scene_mb,
+            "nodes_per_ray": tot[2] / max(rays_per_frame, 1), "tris_per_ray": tot[3] / max(rays_per_frame, 1),
+            # lanes doing a node step / a leaf test per wave-level step of the traversal loop (rank 0's
+            # share; diagnostics of the counted pass)
+            "lanes_per_node_step": st.nodes_visited / max(st.reserved[0], 1),
+            "leaf_phases_per_node_step": st.reserved[1] / max(st.reserved[0], 1),
+            "lanes_at_leaf_per_node_step": st.reserved[2] / max(st.reserved[0], 1),
+            "lanes_without_ray_per_node_step": st.reserved[3] / max(st.reserved[0], 1),
+            "note": ("HBM-bound reading: measured FETCH/WRITE bytes; a scene below 256 MB is partly served by the Infinity "
+                     "Cache, whose hits these fabric-side counters still count" if args.workload in HBM_BOUND else
+                     "cache-resident scene: the binding unit is VALU issue under divergence, not any bandwidth; "
+                     "frac = SQ_INSTS_VALU / s over 1024 SIMDs x 2.4 GHz / 2"),
+        })
+        if pmc:
+            roof["counters_per_launch"] = pmc
         res = {
-            "metric": "Mrays/s (primary+secondary) at 1024x1024/128spp path trace",
+            "metric": metric_text(args.workload),
             "value": rays_per_frame * args.steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,29 +385,22 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s scene (%d triangles), %dx%d, -m %d -N %d, pixel RNG seed 1, %s"
                                    % (args.workload, kind, scene.desc.n_triangles, w, h, mode, spp, args.accel),
-                       "parallelism": "tiles32x%d" % world,
+                       "parallelism": "tiles32x%d, owned tiles gathered to rank 0" % world,
                        "rays_per_frame": rays_per_frame, "samples_per_frame": tot[4],
                        "knn_queries_per_frame": tot[5]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # what HBM actually carried (PMC bytes / the same kernel time): the honest utilisation
-                         "traffic_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic and avg_ms > 0 else None,
-                         "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
-                         "kernel": "k_render", "kernel_ms_avg": avg_ms, "launches": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "nodes_per_ray": tot[2] / max(rays_per_frame, 1), "tris_per_ray": tot[3] / max(rays_per_frame, 1),
-                         # lanes doing a node step / a leaf test per wave-level step of the traversal
-                         # loop (rank 0's share; diagnostics of the counted pass)
-                         "lanes_per_node_step": st.nodes_visited / max(st.reserved[0], 1),
-                         "leaf_phases_per_node_step": st.reserved[1] / max(st.reserved[0], 1),
-                         "lanes_at_leaf_per_node_step": st.reserved[2] / max(st.reserved[0], 1),
-                         "lanes_without_ray_per_node_step": st.reserved[3] / max(st.reserved[0], 1),
-                         "note": "scene is %.2f MB (L2/Infinity-Cache resident): achieved is the ALGORITHMIC byte rate, "
-                                 "served mostly by caches; traffic = measured HBM bytes per launch"
-                                 % ((32 * ctx.bvh_info().n_nodes + 48 * scene.desc.n_triangles) / 1e6)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(kind, mode, spp)
+            cb = cpu_baseline(ctx, kind, mode, dev)
+            gpu_bvh = res["value"]
+            cb["decomposition"] = {
+                "gpu_bvh_over_reference_1thread": gpu_bvh / cb["value"],
+                "hardware_loop_over_loop": (cb["gpu_loop_value"] / cb["value"]) if cb.get("gpu_loop_value") else None,
+                "hardware_bvh_over_bvh_1thread": gpu_bvh / cb["port_bvh_value"],
+                "hardware_bvh_over_bvh_all_cores": gpu_bvh / cb["port_bvh_all_cores_value"],
+                "algorithm_bvh_over_loop_on_cpu": cb["port_bvh_value"] / cb["port_loop_value"],
+            }
+            res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
     ctx.close()
     rdist.shutdown()

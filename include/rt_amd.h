@@ -177,6 +177,37 @@ int rt_resolve_device(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp
                       const void* d_accum, const void* d_background_rgb,
                       void* d_out_rgb, void* stream);
 
+/* ---- multi-GPU (Renderer.cpp:219-265 sharded by pixel tiles) -------------
+ * A tile-sharded frame: rank r of `world` integrates the pixels whose `tile`-pixel granule
+ * (tx + ty) mod world == r (rt_params.rank/world/tile) into its own zeroed full-frame
+ * accumulator.  Assembly moves only what a rank owns: its 8x8-pixel granules, packed
+ * [granule][64] float4 in row-major granule order (n = rt_owned_granules), travel to the
+ * assembling rank, which scatters them into its frame.  One process per GPU
+ * (torch.distributed / MPI) uses the three calls below around its own collective;
+ * one process driving N GPUs uses rt_group_*. */
+int rt_owned_granules(const rt_params* p, uint32_t rank, uint32_t* n_out);
+int rt_pack_owned_device(rt_ctx* ctx, const rt_params* p, const void* d_accum,
+                         void* d_packed /* n*64 float4, device */, void* stream);
+int rt_unpack_owned_device(rt_ctx* ctx, const rt_params* p, uint32_t from_rank,
+                           const void* d_packed, void* d_accum, void* stream);
+
+/* N devices driven from ONE host thread: the scene is replicated (rt_create per device),
+ * every device integrates its tiles concurrently, owned granules go to devices[0] over
+ * xGMI — RCCL ncclSend/ncclRecv (librccl.so, loaded on first use) when all devices are
+ * distinct, peer copies when ranks share a device — and devices[0] resolves.  The image is
+ * bit-identical to rt_render's on one device.  rt_params.rank/world are ignored (set per
+ * device); tile = 0 selects 32. */
+typedef struct rt_group rt_group;
+int rt_group_create(const rt_scene_desc* scene, const int32_t* devices, uint32_t n,
+                    const rt_options* opt, rt_group** out);
+void rt_group_destroy(rt_group* g);
+uint32_t rt_group_size(const rt_group* g);
+int rt_group_uses_rccl(const rt_group* g);
+rt_ctx* rt_group_ctx(rt_group* g, uint32_t rank); /* borrowed: e.g. rt_emit_photons on rank 0 */
+int rt_group_set_photons(rt_group* g, const float* pos3, const float* dir3, uint32_t n);
+int rt_group_render(rt_group* g, const rt_params* p, const float* background_rgb,
+                    float* out_rgb, float* accum_out, rt_stats* stats);
+
 /* Ray origins: the BVH's exactness argument (box padding vs the float triangle test's
  * error) covers origins up to 16 x max(|scene coordinate|, |camera|, |light position|);
  * rays that start farther out are answered by the exhaustive loop, transparently. */

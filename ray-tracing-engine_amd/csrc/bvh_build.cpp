@@ -473,7 +473,11 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   // is what limits occupancy on big scenes; 3 spare levels keep SAH within 1 % of the
   // unconstrained tree (stress scene: depth 25 -> 22, cost 2203 -> 2221; 2 spare: 2562).
   const char* slack = getenv("RT_BVH_SLACK");
-  B.depthCap = std::min(kMaxDepth - 1, B.levelsFor(sc.n_triangles) + (slack ? atoi(slack) : 3));
+  // balanced depth + 3; + 2 for scenes whose trees are 20+ levels deep anyway: one level is
+  // 256 B of LDS per wave, and at 21 levels (+ the sentinel row) 16 waves with their ray pools
+  // still fit a CU's 160 KiB, at 22 only 15 do (1 M triangles: -3 % rays/s; SAH cost +0.4 %)
+  const int defSlack = B.levelsFor(sc.n_triangles) >= 19 ? 2 : 3;
+  B.depthCap = std::min(kMaxDepth - 1, B.levelsFor(sc.n_triangles) + (slack ? atoi(slack) : defSlack));
   B.prims.resize(sc.n_triangles);
   out.trisRef.resize(sc.n_triangles);
   float maxAbs = 0.f;

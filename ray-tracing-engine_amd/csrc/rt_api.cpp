@@ -4,8 +4,12 @@
 // and nothing falls back to the CPU when a device is missing.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <chrono>
 #include <cmath>
+#include <map>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -92,6 +96,12 @@ struct rt_ctx {
   TileKey tileKey;
   unsigned long long* dCounters = nullptr;
   uint32_t* dTileCounter = nullptr;  // work queue head of the persistent render kernel
+  // owned-granule lists of the ranks of a tile-sharded frame (multi-GPU assembly), by key
+  struct GranList {
+    uint32_t* d = nullptr;
+    uint32_t n = 0;
+  };
+  std::map<std::string, GranList> granules;
   uint32_t numCUs = 0;
   hipEvent_t ev[kEventPairs][2];
   int evUsed = 0;
@@ -161,6 +171,40 @@ int ensure_tiles(rt_ctx* c, const rt_params* p, uint32_t sshift) {
   if (rc != RT_OK) return rc;
   c->nTiles = static_cast<uint32_t>(tiles.size());
   c->tileKey = k;
+  return RT_OK;
+}
+
+// The 8x8-pixel granules rank `rank` of `world` owns, row-major — the order ensure_tiles
+// renders them in and the order of the packed exchange buffer.
+void owned_granules(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t tile, std::vector<uint32_t>* out,
+                    uint32_t* count) {
+  if (tile == 0) tile = 8;
+  if (world == 0) world = 1;
+  uint32_t n = 0;
+  const uint32_t gx = (w + 7) / 8, gy = (h + 7) / 8;
+  for (uint32_t y8 = 0; y8 < gy; ++y8)
+    for (uint32_t x8 = 0; x8 < gx; ++x8) {
+      if (world > 1 && (x8 * 8 / tile + y8 * 8 / tile) % world != rank) continue;
+      if (out) out->push_back(x8 | (y8 << 16));
+      ++n;
+    }
+  if (count) *count = n;
+}
+
+int ensure_granules(rt_ctx* c, const rt_params* p, uint32_t rank, rt_ctx::GranList* out) {
+  char key[96];
+  snprintf(key, sizeof key, "%u.%u.%u.%u.%u", p->width, p->height, rank, p->world ? p->world : 1, p->tile ? p->tile : 8);
+  auto it = c->granules.find(key);
+  if (it == c->granules.end()) {
+    std::vector<uint32_t> g;
+    owned_granules(p->width, p->height, rank, p->world, p->tile, &g, nullptr);
+    rt_ctx::GranList L;
+    int rc = upload(&L.d, g.data(), g.size());
+    if (rc != RT_OK) return rc;
+    L.n = static_cast<uint32_t>(g.size());
+    it = c->granules.emplace(key, L).first;
+  }
+  *out = it->second;
   return RT_OK;
 }
 
@@ -348,6 +392,8 @@ void rt_destroy(rt_ctx* c) {
   if (c->dTiles) (void)hipFree(c->dTiles);
   if (c->dCounters) (void)hipFree(c->dCounters);
   if (c->dTileCounter) (void)hipFree(c->dTileCounter);
+  for (auto& kv : c->granules)
+    if (kv.second.d) (void)hipFree(kv.second.d);
   if (c->evReady)
     for (auto& pr : c->ev) (void)hipEventDestroy(pr[0]), (void)hipEventDestroy(pr[1]);
   delete c;
@@ -660,6 +706,289 @@ int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint
   (void)hipFree(dIn);
   if (dOut) (void)hipFree(dOut);
   if (he != hipSuccess) return fail(RT_ERR_HIP, "unit kernel failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU frame assembly
+int rt_owned_granules(const rt_params* p, uint32_t rank, uint32_t* n_out) {
+  if (!p || !n_out) return fail(RT_ERR_INVALID, "null argument");
+  if (p->tile % 8 != 0) return fail(RT_ERR_INVALID, "tile must be a multiple of 8");
+  owned_granules(p->width, p->height, rank, p->world, p->tile, nullptr, n_out);
+  return RT_OK;
+}
+
+int rt_pack_owned_device(rt_ctx* c, const rt_params* p, const void* d_accum, void* d_packed, void* stream) {
+  if (!c || !p || !d_accum || !d_packed) return fail(RT_ERR_INVALID, "null argument");
+  if (p->tile % 8 != 0 || (p->world > 1 && p->rank >= p->world)) return fail(RT_ERR_INVALID, "bad rank/world/tile");
+  HIP_TRY(hipSetDevice(c->device));
+  rt_ctx::GranList L;
+  int rc = ensure_granules(c, p, p->rank, &L);
+  if (rc != RT_OK) return rc;
+  hipError_t he = rtk::launch_pack(false, static_cast<const float4*>(d_accum), static_cast<float4*>(d_packed), L.d, L.n, p->width,
+                                   p->height, static_cast<hipStream_t>(stream));
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "pack launch failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
+int rt_unpack_owned_device(rt_ctx* c, const rt_params* p, uint32_t from_rank, const void* d_packed, void* d_accum, void* stream) {
+  if (!c || !p || !d_accum || !d_packed) return fail(RT_ERR_INVALID, "null argument");
+  if (p->tile % 8 != 0 || from_rank >= (p->world ? p->world : 1)) return fail(RT_ERR_INVALID, "bad rank/world/tile");
+  HIP_TRY(hipSetDevice(c->device));
+  rt_ctx::GranList L;
+  int rc = ensure_granules(c, p, from_rank, &L);
+  if (rc != RT_OK) return rc;
+  hipError_t he = rtk::launch_pack(true, static_cast<const float4*>(d_packed), static_cast<float4*>(d_accum), L.d, L.n, p->width,
+                                   p->height, static_cast<hipStream_t>(stream));
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "unpack launch failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ rt_group: N devices, one process
+// RCCL is reached through dlopen: single-GPU users of librt_amd.so never load it.
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load() {
+    if (lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) return false;
+#define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name))
+    SYM(CommInitAll, "ncclCommInitAll");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return CommInitAll && CommDestroy && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+  }
+};
+Rccl g_rccl;
+}  // namespace
+
+struct rt_group {
+  std::vector<rt_ctx*> ctx;
+  std::vector<int> dev;
+  std::vector<hipStream_t> stream;
+  std::vector<hipEvent_t> packed_ready;
+  std::vector<float4*> accum;   // [rank] full frame on that rank's device
+  std::vector<float4*> packed;  // [rank] owned granules, on that rank's device (rank > 0)
+  std::vector<float4*> recv;    // [rank] the same bytes on device 0 (rank > 0)
+  std::vector<ncclComm_t> comm; // RCCL communicators (all devices distinct), else empty: peer copies
+  float *dBg = nullptr, *dOut = nullptr;
+  size_t npx = 0;
+  uint32_t fw = 0, fh = 0, ftile = 0;  // what the frame buffers are sized for
+  uint32_t tile = 32;
+  bool rccl = false;
+};
+
+namespace {
+void group_free_frame(rt_group* g) {
+  for (size_t r = 0; r < g->ctx.size(); ++r) {
+    (void)hipSetDevice(g->dev[r]);
+    if (g->accum[r]) (void)hipFree(g->accum[r]);
+    if (g->packed[r]) (void)hipFree(g->packed[r]);
+    g->accum[r] = g->packed[r] = nullptr;
+  }
+  (void)hipSetDevice(g->dev[0]);
+  for (auto& p : g->recv) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+  if (g->dBg) (void)hipFree(g->dBg);
+  if (g->dOut) (void)hipFree(g->dOut);
+  g->dBg = g->dOut = nullptr;
+  g->npx = 0, g->fw = g->fh = g->ftile = 0;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_group_create(const rt_scene_desc* scene, const int32_t* devices, uint32_t n, const rt_options* opt, rt_group** out) {
+  if (!scene || !devices || !out || n == 0) return fail(RT_ERR_INVALID, "scene/devices/out is null or n == 0");
+  if (n > 64) return fail(RT_ERR_INVALID, "at most 64 devices");
+  *out = nullptr;
+  rt_group* g = new rt_group();
+  bool distinct = true;
+  for (uint32_t r = 0; r < n; ++r)
+    for (uint32_t q = 0; q < r; ++q) distinct = distinct && devices[r] != devices[q];
+  for (uint32_t r = 0; r < n; ++r) {
+    rt_options o{};
+    if (opt) o = *opt;
+    o.device = devices[r];
+    rt_ctx* c = nullptr;
+    int rc = rt_create(scene, &o, &c);
+    hipStream_t s = nullptr;
+    hipEvent_t e = nullptr;
+    if (rc == RT_OK && (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess))
+      rc = fail(RT_ERR_HIP, "stream/event creation failed on device %d", devices[r]);
+    if (rc != RT_OK) {
+      const std::string keep = g_err;
+      if (c) rt_destroy(c);
+      rt_group_destroy(g);
+      g_err = keep;
+      return rc;
+    }
+    g->ctx.push_back(c), g->dev.push_back(devices[r]), g->stream.push_back(s), g->packed_ready.push_back(e);
+  }
+  g->accum.assign(n, nullptr), g->packed.assign(n, nullptr), g->recv.assign(n, nullptr);
+  // exchange path: RCCL send/recv when every rank has its own device (ncclCommInitAll refuses
+  // duplicates); ranks sharing a device (rehearsal on one GPU) use peer copies
+  if (((n > 1 && distinct) || (n == 1 && getenv("RT_GROUP_FORCE_RCCL"))) && !getenv("RT_GROUP_NO_RCCL")) {
+    if (!g_rccl.load()) {
+      rt_group_destroy(g);
+      return fail(RT_ERR_UNSUPPORTED, "librccl.so could not be loaded (%s); set RT_GROUP_NO_RCCL=1 for peer copies", dlerror());
+    }
+    g->comm.assign(n, nullptr);
+    ncclResult_t nr = g_rccl.CommInitAll(g->comm.data(), static_cast<int>(n), g->dev.data());
+    if (nr != ncclSuccess) {
+      g->comm.clear();
+      rt_group_destroy(g);
+      return fail(RT_ERR_HIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(nr));
+    }
+    g->rccl = true;
+  }
+  *out = g;
+  return RT_OK;
+}
+
+void rt_group_destroy(rt_group* g) {
+  if (!g) return;
+  if (!g->ctx.empty()) group_free_frame(g);
+  for (ncclComm_t c : g->comm)
+    if (c) (void)g_rccl.CommDestroy(c);
+  for (size_t r = 0; r < g->ctx.size(); ++r) {
+    (void)hipSetDevice(g->dev[r]);
+    if (g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
+    if (g->packed_ready[r]) (void)hipEventDestroy(g->packed_ready[r]);
+    rt_destroy(g->ctx[r]);
+  }
+  delete g;
+}
+
+uint32_t rt_group_size(const rt_group* g) { return g ? static_cast<uint32_t>(g->ctx.size()) : 0; }
+int rt_group_uses_rccl(const rt_group* g) { return g && g->rccl ? 1 : 0; }
+rt_ctx* rt_group_ctx(rt_group* g, uint32_t rank) { return g && rank < g->ctx.size() ? g->ctx[rank] : nullptr; }
+
+int rt_group_set_photons(rt_group* g, const float* pos3, const float* dir3, uint32_t n) {
+  if (!g) return fail(RT_ERR_INVALID, "group is null");
+  for (rt_ctx* c : g->ctx) {
+    int rc = rt_set_photons(c, pos3, dir3, n);
+    if (rc != RT_OK) return rc;
+  }
+  return RT_OK;
+}
+
+int rt_group_render(rt_group* g, const rt_params* p, const float* bg, float* out_rgb, float* accum_out, rt_stats* stats) {
+  if (!g) return fail(RT_ERR_INVALID, "group is null");
+  const uint32_t n = static_cast<uint32_t>(g->ctx.size());
+  int rc = check_params(g->ctx[0], p);
+  if (rc != RT_OK) return rc;
+  if (out_rgb && !bg) return fail(RT_ERR_INVALID, "out_rgb requested without a background image");
+  const size_t npx = (size_t)p->width * p->height;
+  rt_params base = *p;
+  base.world = n, base.tile = p->tile ? p->tile : g->tile;
+  std::vector<uint32_t> cnt(n, 0);
+  for (uint32_t r = 0; r < n; ++r) owned_granules(p->width, p->height, r, n, base.tile, nullptr, &cnt[r]);
+  if (p->width != g->fw || p->height != g->fh || base.tile != g->ftile) {  // frame buffers for this image size and sharding
+    group_free_frame(g);
+    for (uint32_t r = 0; r < n; ++r) {
+      HIP_TRY(hipSetDevice(g->dev[r]));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->accum[r]), npx * sizeof(float4)));
+      if (r > 0 && cnt[r]) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->packed[r]), (size_t)cnt[r] * 64 * sizeof(float4)));
+    }
+    HIP_TRY(hipSetDevice(g->dev[0]));
+    for (uint32_t r = 1; r < n; ++r)
+      if (cnt[r]) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->recv[r]), (size_t)cnt[r] * 64 * sizeof(float4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->dBg), npx * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->dOut), npx * 3 * sizeof(float)));
+    g->npx = npx, g->fw = p->width, g->fh = p->height, g->ftile = base.tile;
+  }
+  // 1. every rank integrates its tiles (asynchronously, each on its own device and stream)
+  std::vector<int> ev(n, 0);
+  for (uint32_t r = 0; r < n; ++r) {
+    rt_params pr = base;
+    pr.rank = r;
+    HIP_TRY(hipSetDevice(g->dev[r]));
+    HIP_TRY(hipMemsetAsync(g->accum[r], 0, npx * sizeof(float4), g->stream[r]));
+    HIP_TRY(hipMemsetAsync(g->ctx[r]->dCounters, 0, RTK_CNT_COUNT * sizeof(unsigned long long), g->stream[r]));
+    rc = launch_frame(g->ctx[r], &pr, g->accum[r], g->stream[r], &ev[r]);
+    if (rc != RT_OK) return rc;
+    if (r > 0 && cnt[r]) {
+      rc = rt_pack_owned_device(g->ctx[r], &pr, g->accum[r], g->packed[r], g->stream[r]);
+      if (rc != RT_OK) return rc;
+      HIP_TRY(hipEventRecord(g->packed_ready[r], g->stream[r]));
+    }
+  }
+  // 2. owned granules travel to rank 0's device: 1/N of the frame per rank, nothing else
+  if (g->rccl) {
+    ncclResult_t nr = g_rccl.GroupStart();
+    for (uint32_t r = 1; r < n && nr == ncclSuccess; ++r) {
+      if (!cnt[r]) continue;
+      const size_t floats = (size_t)cnt[r] * 64 * 4;
+      nr = g_rccl.Send(g->packed[r], floats, ncclFloat, 0, g->comm[r], g->stream[r]);
+      if (nr == ncclSuccess) nr = g_rccl.Recv(g->recv[r], floats, ncclFloat, static_cast<int>(r), g->comm[0], g->stream[0]);
+    }
+    const ncclResult_t ne = g_rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return fail(RT_ERR_HIP, "RCCL exchange failed: %s", g_rccl.GetErrorString(nr));
+  } else {
+    HIP_TRY(hipSetDevice(g->dev[0]));
+    for (uint32_t r = 1; r < n; ++r) {
+      if (!cnt[r]) continue;
+      HIP_TRY(hipStreamWaitEvent(g->stream[0], g->packed_ready[r], 0));
+      HIP_TRY(hipMemcpyPeerAsync(g->recv[r], g->dev[0], g->packed[r], g->dev[r], (size_t)cnt[r] * 64 * sizeof(float4), g->stream[0]));
+    }
+  }
+  // 3. rank 0 scatters them into its frame, resolves (Renderer.cpp:262-265) and hands the image back
+  HIP_TRY(hipSetDevice(g->dev[0]));
+  for (uint32_t r = 1; r < n; ++r) {
+    if (!cnt[r]) continue;
+    rc = rt_unpack_owned_device(g->ctx[0], &base, r, g->recv[r], g->accum[0], g->stream[0]);
+    if (rc != RT_OK) return rc;
+  }
+  hipError_t he = hipSuccess;
+  if (out_rgb) {
+    he = hipMemcpyAsync(g->dBg, bg, npx * 3 * sizeof(float), hipMemcpyHostToDevice, g->stream[0]);
+    if (he == hipSuccess) rc = rt_resolve_device(g->ctx[0], p->width, p->height, p->spp, g->accum[0], g->dBg, g->dOut, g->stream[0]);
+    if (rc != RT_OK) return rc;
+    if (he == hipSuccess) he = hipMemcpyAsync(out_rgb, g->dOut, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, g->stream[0]);
+  }
+  if (he == hipSuccess && accum_out) he = hipMemcpyAsync(accum_out, g->accum[0], npx * sizeof(float4), hipMemcpyDeviceToHost, g->stream[0]);
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "frame read-back failed: %s", hipGetErrorString(he));
+  for (uint32_t r = 0; r < n; ++r) {
+    HIP_TRY(hipSetDevice(g->dev[r]));
+    HIP_TRY(hipStreamSynchronize(g->stream[r]));
+  }
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    for (uint32_t r = 0; r < n; ++r) {
+      HIP_TRY(hipSetDevice(g->dev[r]));
+      rt_stats s{};
+      rc = read_counters(g->ctx[r], &s);
+      if (rc != RT_OK) return rc;
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, g->ctx[r]->ev[ev[r]][0], g->ctx[r]->ev[ev[r]][1]));
+      stats->rays_closest += s.rays_closest, stats->rays_shadow += s.rays_shadow, stats->knn_queries += s.knn_queries;
+      stats->nodes_visited += s.nodes_visited, stats->tris_tested += s.tris_tested, stats->kd_visited += s.kd_visited;
+      stats->kernel_ms = ms > stats->kernel_ms ? ms : stats->kernel_ms;  // the slowest rank
+    }
+    stats->samples = (uint64_t)npx * (p->spp_count ? p->spp_count : p->spp);
+  }
   return RT_OK;
 }
 

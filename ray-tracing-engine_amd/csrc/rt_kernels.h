@@ -67,6 +67,10 @@ hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevSce
                          float4* accum, unsigned long long* counters, hipStream_t stream);
 hipError_t launch_resolve(uint32_t n_pixels, uint32_t spp, const float4* accum, const float* bg, float* out,
                           hipStream_t stream);
+// multi-GPU frame assembly: pack (unpack = false) a rank's owned granules out of a full-frame
+// accumulator, or scatter a packed buffer back into one
+hipError_t launch_pack(bool unpack, const float4* src, float4* dst, const uint32_t* gran, uint32_t n, uint32_t width,
+                       uint32_t height, hipStream_t stream);
 hipError_t launch_trace(bool brute_force, bool any, const DevScene& S, const rt_ray* rays, uint32_t n,
                         rt_hit* hits, unsigned long long* counters, hipStream_t stream);
 hipError_t launch_knn(const DevScene& S, const float* q, uint32_t n, uint32_t k, uint32_t* idx, float* dist,

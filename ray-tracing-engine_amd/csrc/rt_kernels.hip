@@ -1019,6 +1019,25 @@ __global__ void k_resolve(uint32_t n_pixels, float spp, const float4* __restrict
   out[3 * i + 2] = a.z / spp + bg[3 * i + 2] * miss / spp;
 }
 
+// ---------------------------------------------------------------- frame assembly (multi-GPU)
+// A rank's owned 8x8-pixel granules, packed [granule][64 pixels] (row-major inside the
+// granule; slots outside the image are never read back), and the inverse on the rank
+// that assembles the frame.  gran[g] = x8 | y8 << 16 (granule coordinates).
+__global__ void k_pack_owned(const float4* __restrict__ accum, float4* __restrict__ packed, const uint32_t* __restrict__ gran,
+                             uint32_t n, uint32_t width, uint32_t height) {
+  const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+  if (g >= n) return;
+  const uint32_t x = (gran[g] & 0xffffu) * 8u + (l & 7u), y = (gran[g] >> 16) * 8u + (l >> 3);
+  packed[(size_t)g * 64u + l] = (x < width && y < height) ? accum[(size_t)y * width + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void k_unpack_owned(const float4* __restrict__ packed, float4* __restrict__ accum, const uint32_t* __restrict__ gran,
+                               uint32_t n, uint32_t width, uint32_t height) {
+  const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+  if (g >= n) return;
+  const uint32_t x = (gran[g] & 0xffffu) * 8u + (l & 7u), y = (gran[g] >> 16) * 8u + (l >> 3);
+  if (x < width && y < height) accum[(size_t)y * width + x] = packed[(size_t)g * 64u + l];
+}
+
 // ---------------------------------------------------------------- test hooks
 template <bool BRUTE, bool ANY>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, const rt_ray* __restrict__ rays, uint32_t n,
@@ -1316,6 +1335,15 @@ hipError_t launch_resolve(uint32_t n_pixels, uint32_t spp, const float4* accum, 
   if (n_pixels == 0) return hipSuccess;
   hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, n_pixels, (float)spp, accum,
                      bg, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack(bool unpack, const float4* src, float4* dst, const uint32_t* gran, uint32_t n, uint32_t width,
+                       uint32_t height, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const dim3 grid((n + 3) / 4), block(256);
+  if (unpack) hipLaunchKernelGGL(k_unpack_owned, grid, block, 0, stream, src, dst, gran, n, width, height);
+  else hipLaunchKernelGGL(k_pack_owned, grid, block, 0, stream, src, dst, gran, n, width, height);
   return hipGetLastError();
 }
 

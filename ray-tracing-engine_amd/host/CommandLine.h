@@ -4,7 +4,8 @@
 // 380x270, N=16, mode 0, no photons, k=5, output.ppm; a trailing flag without a
 // value is "Missing argument" unless it is -help; unknown flags throw; a mode other
 // than 0/1 silently becomes 0), plus build-defined extensions the reference has
-// no equivalent for: -scene, -meshdir, -seed, -gpu, -accel, -progress.
+// no equivalent for: -scene, -meshdir, -seed, -gpu, -gpus, -devices, -accel,
+// -progress.
 #pragma once
 
 #include <cstdlib>
@@ -18,7 +19,7 @@ class CommandLine {
  public:
   CommandLine()
       : m_width(380), m_height(270), m_numRays(16), m_mode(0), m_numPhotons(0), m_k(5), m_seed(1), m_gpu(0),
-        m_accel(0), m_progress(0), m_outputFilename("output.ppm"), m_scene("cubes"), m_meshDir("../meshes") {}
+        m_accel(0), m_progress(0), m_gpus(1), m_outputFilename("output.ppm"), m_scene("cubes"), m_meshDir("../meshes") {}
   virtual ~CommandLine() {}
 
   size_t width() const { return m_width; }
@@ -33,6 +34,8 @@ class CommandLine {
   size_t gpu() const { return m_gpu; }
   size_t accel() const { return m_accel; }
   size_t progress() const { return m_progress; }
+  size_t gpus() const { return m_gpus; }
+  const std::string& devices() const { return m_devices; }
   const std::string& scene() const { return m_scene; }
   const std::string& meshDir() const { return m_meshDir; }
 
@@ -43,7 +46,8 @@ class CommandLine {
                  "tracing)>][-p/-numPhotons <number of photons for a photon map. If defined, photon map-based "
                  "rendering is used.>][-k <number of neighbours in photon mapping. Use only with -p/-numPhotons>]"
                  "[-scene <cubes|lowres|hires|stress|file:NAME.off>][-meshdir <dir with .off files>]"
-                 "[-seed <per-pixel RNG stream key>][-gpu <HIP device>][-accel <0 BVH | 1 brute force>]"
+                 "[-seed <per-pixel RNG stream key>][-gpu <HIP device>][-gpus <N: tile-shard the frame over devices gpu..gpu+N-1>]"
+                 "[-devices <a,b,c: explicit device list for -gpus>][-accel <0 BVH | 1 brute force>]"
                  "[-progress <samples per update.ppm; 1 = after every pass like the reference, 0 = once>]"
               << std::endl;
   }
@@ -70,6 +74,8 @@ class CommandLine {
       else if (flag == "-meshdir") m_meshDir = value;
       else if (flag == "-seed") m_seed = std::atoi(value);
       else if (flag == "-gpu") m_gpu = std::atoi(value);
+      else if (flag == "-gpus") m_gpus = std::atoi(value);
+      else if (flag == "-devices") m_devices = value;
       else if (flag == "-accel") m_accel = std::atoi(value);
       else if (flag == "-progress") m_progress = std::atoi(value);
       else throw std::runtime_error("Unknown argument <" + flag + ">");
@@ -86,6 +92,6 @@ class CommandLine {
   }
 
  private:
-  size_t m_width, m_height, m_numRays, m_mode, m_numPhotons, m_k, m_seed, m_gpu, m_accel, m_progress;
-  std::string m_outputFilename, m_scene, m_meshDir;
+  size_t m_width, m_height, m_numRays, m_mode, m_numPhotons, m_k, m_seed, m_gpu, m_accel, m_progress, m_gpus;
+  std::string m_outputFilename, m_scene, m_meshDir, m_devices;
 };

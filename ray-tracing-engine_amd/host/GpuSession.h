@@ -7,6 +7,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "SceneFlatten.h"
 #include "rt_amd.h"
@@ -46,6 +47,28 @@ class GpuSession {
   rt_ctx* m_ctx;
 };
 
+// N devices behind one Renderer::render (rt_group: replicated scene, tile-sharded frame,
+// owned tiles to devices[0] over xGMI)
+class GpuGroupSession {
+ public:
+  GpuGroupSession(const Scene& scene, const std::vector<int>& devices) : m_flat(scene), m_group(nullptr) {
+    std::vector<int32_t> d(devices.begin(), devices.end());
+    GpuSession::check(rt_group_create(&m_flat.desc, d.data(), static_cast<uint32_t>(d.size()), nullptr, &m_group),
+                      "rt_group_create");
+  }
+  ~GpuGroupSession() {
+    if (m_group) rt_group_destroy(m_group);
+  }
+  GpuGroupSession(const GpuGroupSession&) = delete;
+  GpuGroupSession& operator=(const GpuGroupSession&) = delete;
+  rt_group* group() const { return m_group; }
+  rt_ctx* ctx0() const { return rt_group_ctx(m_group, 0); }
+
+ private:
+  FlatScene m_flat;
+  rt_group* m_group;
+};
+
 // process-wide settings the reference has no place for (set by Main.cpp's extra
 // flags; defaults reproduce `./RayTracer` without them)
 struct GpuSettings {
@@ -53,6 +76,7 @@ struct GpuSettings {
   unsigned seed = 1;
   unsigned accel = RT_ACCEL_BVH;
   unsigned progress = 0;  // samples per launch / per update.ppm (0 = whole frame at once)
+  std::vector<int> devices;  // more than one entry: Renderer::render tile-shards the frame over them (rt_group)
   static GpuSettings& get() {
     static GpuSettings s;
     return s;

@@ -26,6 +26,20 @@ int main(int argc, char** argv) {
   GpuSettings::get().seed = static_cast<unsigned>(args.seed());
   GpuSettings::get().accel = args.accel() ? RT_ACCEL_BRUTE : RT_ACCEL_BVH;
   GpuSettings::get().progress = static_cast<unsigned>(args.progress());
+  // -gpus N: devices gpu..gpu+N-1; -devices a,b,c: an explicit list (may repeat a device:
+  // rehearsal of the N-rank flow on one GPU)
+  if (!args.devices().empty()) {
+    size_t pos = 0;
+    const std::string& d = args.devices();
+    while (pos <= d.size()) {
+      const size_t c = d.find(',', pos);
+      GpuSettings::get().devices.push_back(std::atoi(d.substr(pos, c == std::string::npos ? c : c - pos).c_str()));
+      if (c == std::string::npos) break;
+      pos = c + 1;
+    }
+  } else if (args.gpus() > 1) {
+    for (size_t i = 0; i < args.gpus(); ++i) GpuSettings::get().devices.push_back(static_cast<int>(args.gpu() + i));
+  }
 
   try {
     Image image(args.width(), args.height());

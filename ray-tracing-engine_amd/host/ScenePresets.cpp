@@ -29,8 +29,9 @@ void appendQuad(Mesh& mesh, const Quad& q) {
 
 // C5: one mesh of 83,334 scaled/translated copies of `unit` on a 44^3 lattice,
 // lexicographic cell order, no randomness (SURVEY.md §8d "stress scene").
-Mesh latticeOfCopies(const Mesh& unit) {
-  const int G = 44, copies = 83334;
+// ("stress8": the same on an 88^3 lattice, 666,672 copies = 8.0 M triangles — a supplementary
+// point whose node + triangle arrays (0.5 GB) exceed the 256 MB Infinity Cache.)
+Mesh latticeOfCopies(const Mesh& unit, int G, int copies) {
   const float lo[3] = {-1.4f, -0.95f, -1.4f}, hi[3] = {1.4f, 1.4f, 1.0f};
   Vec3f bmin = unit.vertexPositions()[0], bmax = bmin;
   for (const Vec3f& p : unit.vertexPositions())
@@ -100,7 +101,7 @@ Scene buildCornellScene(const std::string& kind, const std::string& meshDir, siz
   if (kind == "cubes") file3 = "cube_tri.off";
   else if (kind == "lowres") file3 = "example_low_res.off";
   else if (kind == "hires") file3 = "example.off";
-  else if (kind == "stress") file3 = "cube_tri.off", lattice = true;
+  else if (kind == "stress" || kind == "stress8") file3 = "cube_tri.off", lattice = true;
   else if (kind.rfind("file:", 0) == 0) file3 = kind.substr(5);
   else throw std::runtime_error("unknown scene kind '" + kind + "'");
   slot3.loadOFF(meshDir + "/" + file3);
@@ -114,7 +115,7 @@ Scene buildCornellScene(const std::string& kind, const std::string& meshDir, siz
   appendQuad(rightWall, Quad{{{B, F, B}, {B, F, -B}, {B, C, B}, {B, C, -B}}, {-1.f, 0.f, 0.f}});
 
   if (lattice) {
-    slot3 = latticeOfCopies(slot3);
+    slot3 = kind == "stress8" ? latticeOfCopies(slot3, 88, 666672) : latticeOfCopies(slot3, 44, 83334);
   } else {
     rotationY(slot3, static_cast<float>(3.14159265358979323846 / 4.5f));
   }

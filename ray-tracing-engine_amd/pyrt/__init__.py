@@ -86,7 +86,9 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("mesh", "<u4"), ("tri", "<u4"), ("vtx", "
 # every symbol include/rt_amd.h / include/rt_host.h declares
 AMD_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_photons", "rt_emit_photons",
                "rt_render", "rt_render_passes", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
-               "rt_bvh_export", "rt_bvh_build_host", "rt_profile_reset", "rt_profile_collect", "rt_test_unit"]
+               "rt_bvh_export", "rt_bvh_build_host", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
+               "rt_owned_granules", "rt_pack_owned_device", "rt_unpack_owned_device", "rt_group_create", "rt_group_destroy",
+               "rt_group_size", "rt_group_uses_rccl", "rt_group_ctx", "rt_group_set_photons", "rt_group_render"]
 HOST_SYMBOLS = ["rt_host_scene_build", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error",
                 "rt_host_fill_background", "rt_host_save_ppm", "rt_host_kd_order"]
 
@@ -136,6 +138,20 @@ def amd():
         L.rt_profile_reset.argtypes = [C.c_void_p]
         L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.rt_test_unit.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.rt_owned_granules.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_uint32)]
+        L.rt_pack_owned_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_unpack_owned_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_group_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(Options),
+                                      C.POINTER(C.c_void_p)]
+        L.rt_group_destroy.argtypes = [C.c_void_p]
+        L.rt_group_destroy.restype = None
+        L.rt_group_size.argtypes = [C.c_void_p]
+        L.rt_group_size.restype = C.c_uint32
+        L.rt_group_uses_rccl.argtypes = [C.c_void_p]
+        L.rt_group_ctx.argtypes = [C.c_void_p, C.c_uint32]
+        L.rt_group_ctx.restype = C.c_void_p
+        L.rt_group_set_photons.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.rt_group_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         _amd = L
     return _amd
 
@@ -286,6 +302,17 @@ class Context:
         _check(amd().rt_render(self._h, C.byref(params), _ptr(bgc), _ptr(out), _ptr(acc), C.byref(st)))
         return out, acc, st
 
+    def render_passes(self, params, bg, accum_io):
+        """rt_render_passes: integrate params.spp_begin/spp_count on top of accum_io (in place)
+        and resolve the running estimate; returns (out_rgb, stats)."""
+        w, h = params.width, params.height
+        out = np.empty((h, w, 3), np.float32)
+        st = Stats()
+        bgc = np.ascontiguousarray(bg, np.float32)
+        assert accum_io.dtype == np.float32 and accum_io.flags["C_CONTIGUOUS"] and accum_io.shape == (h, w, 4)
+        _check(amd().rt_render_passes(self._h, C.byref(params), _ptr(bgc), _ptr(accum_io), _ptr(out), C.byref(st)))
+        return out, st
+
     def render_device(self, params, d_accum_ptr, stream=0, stats=False):
         st = Stats() if stats else None
         _check(amd().rt_render_device(self._h, C.byref(params), C.c_void_p(d_accum_ptr), C.c_void_p(stream),
@@ -295,6 +322,14 @@ class Context:
     def resolve_device(self, width, height, spp, d_accum_ptr, d_bg_ptr, d_out_ptr, stream=0):
         _check(amd().rt_resolve_device(self._h, width, height, spp, C.c_void_p(d_accum_ptr), C.c_void_p(d_bg_ptr),
                                        C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def pack_owned(self, params, d_accum_ptr, d_packed_ptr, stream=0):
+        _check(amd().rt_pack_owned_device(self._h, C.byref(params), C.c_void_p(d_accum_ptr), C.c_void_p(d_packed_ptr),
+                                          C.c_void_p(stream)))
+
+    def unpack_owned(self, params, from_rank, d_packed_ptr, d_accum_ptr, stream=0):
+        _check(amd().rt_unpack_owned_device(self._h, C.byref(params), from_rank, C.c_void_p(d_packed_ptr),
+                                            C.c_void_p(d_accum_ptr), C.c_void_p(stream)))
 
     def profile_reset(self):
         _check(amd().rt_profile_reset(self._h))
@@ -317,6 +352,55 @@ class Context:
         vis = np.zeros(len(q), np.uint32)
         _check(amd().rt_knn(self._h, _ptr(q), len(q), k, _ptr(idx), _ptr(dist), _ptr(vis)))
         return idx, dist, vis
+
+
+def owned_granules(params, rank):
+    """Number of 8x8-pixel granules `rank` owns in the tile-sharded frame `params` describes."""
+    n = C.c_uint32()
+    _check(amd().rt_owned_granules(C.byref(params), rank, C.byref(n)))
+    return n.value
+
+
+class Group:
+    """rt_group: one process driving N devices (RCCL / peer copies inside librt_amd.so)."""
+
+    def __init__(self, scene, devices, bvh_leaf_max=0):
+        self.scene = scene
+        opt = Options()
+        opt.bvh_leaf_max = bvh_leaf_max
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(amd().rt_group_create(scene.desc_ptr, devs, len(devices), C.byref(opt), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            amd().rt_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def size(self):
+        return amd().rt_group_size(self._h)
+
+    @property
+    def uses_rccl(self):
+        return bool(amd().rt_group_uses_rccl(self._h))
+
+    def set_photons(self, pos, dir_):
+        pos = np.ascontiguousarray(pos, np.float32)
+        dir_ = np.ascontiguousarray(dir_, np.float32)
+        _check(amd().rt_group_set_photons(self._h, _ptr(pos), _ptr(dir_), len(pos)))
+
+    def render(self, params, bg=None, want_accum=True):
+        w, h = params.width, params.height
+        out = np.empty((h, w, 3), np.float32) if bg is not None else None
+        acc = np.empty((h, w, 4), np.float32) if want_accum else None
+        st = Stats()
+        bgc = None if bg is None else np.ascontiguousarray(bg, np.float32)
+        _check(amd().rt_group_render(self._h, C.byref(params), _ptr(bgc), _ptr(out), _ptr(acc), C.byref(st)))
+        return out, acc, st
 
 
 _UNIT_IO = {UNIT_ASIN: (np.float64, 1, np.float64, 1), UNIT_SINF: (np.float32, 1, np.float32, 1),

@@ -4,11 +4,11 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 The path shards by 8x8-pixel tiles (rt_params.rank/world/tile): every rank
 integrates ALL samples of the pixels it owns, in order, into a zero-initialised
 full-frame accumulator {sum r, g, b, primary-hit count}.  The only exchange step
-is one SUM reduce of that accumulator to rank 0 per frame: each pixel is non-zero
-on exactly one rank and adding zeros is exact, so the N-GPU frame is bit-identical
-to the 1-GPU frame.  Message size is w*h*16 B (16 MiB at 1024^2, 64 MiB at 2048^2):
-one ring step over one ~153 GB/s xGMI link is well under a millisecond, which is
-why nothing more elaborate than a single reduce is used.
+is the assembly of the frame on rank 0: FrameAssembler gathers each rank's OWNED
+granules (w*h*16/N bytes per rank: 2 MiB at 1024^2 and 8 ranks, each over its own xGMI
+link to rank 0), so the N-GPU frame is bit-identical to the 1-GPU frame by construction
+— pixels are copied, never summed.  reduce_frame (a full-frame SUM reduce of mostly
+zeros, exact for the same reason) is kept as the reference exchange for the tests.
 """
 import os
 
@@ -51,6 +51,74 @@ def reduce_frame(accum, dst=0):
         else:
             dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
+
+
+def owned_granule_index(width, height, rank, world, tile):
+    """Host statement of the owned-granule order (csrc/rt_api.cpp owned_granules): flat pixel
+    indices [n_granules][64] of rank's 8x8 granules, row-major; -1 outside the image."""
+    import numpy as np
+    gx, gy = (width + 7) // 8, (height + 7) // 8
+    y8, x8 = np.meshgrid(np.arange(gy), np.arange(gx), indexing="ij")
+    own = np.ones_like(x8, bool) if world <= 1 else ((x8 * 8 // tile + y8 * 8 // tile) % world == rank)
+    gxs, gys = x8[own], y8[own]  # row-major order of the boolean mask
+    ly, lx = np.divmod(np.arange(64), 8)
+    px = gxs[:, None] * 8 + lx[None, :]
+    py = gys[:, None] * 8 + ly[None, :]
+    idx = py * width + px
+    idx[(px >= width) | (py >= height)] = -1
+    return idx
+
+
+class FrameAssembler:
+    """Assembles the tile-sharded frame on rank 0 by moving only OWNED pixels: every rank
+    packs its 8x8 granules ([granule][64] float4), one gather brings them to rank 0 (1/N of
+    the frame per rank instead of a full-frame SUM reduce of mostly zeros), rank 0 scatters
+    them.  On a GPU the pack/scatter are the library's kernels (rt_pack_owned_device /
+    rt_unpack_owned_device); on CPU tensors (gloo tests) the same order in numpy."""
+
+    def __init__(self, ctx, params, rank, world, device):
+        self.ctx, self.params, self.rank, self.world = ctx, params, rank, world
+        self.w, self.h, self.tile = params.width, params.height, params.tile or 8
+        self.cuda = torch.device(device).type == "cuda"
+        self.backend = dist.get_backend() if active() else None
+        if world <= 1:
+            return
+        if ctx is not None and self.cuda:
+            import pyrt
+            self.counts = [pyrt.owned_granules(params, r) for r in range(world)]
+        else:
+            self.index = [owned_granule_index(self.w, self.h, r, world, self.tile) for r in range(world)]
+            self.counts = [len(ix) for ix in self.index]
+        self.maxc = max(self.counts)
+        # gloo cannot move device tensors: stage through the host in rehearsal mode
+        self.stage_dev = "cpu" if (self.cuda and self.backend == "gloo") else device
+        self.packed = torch.zeros((self.maxc * 64, 4), dtype=torch.float32, device=device)
+        self.recv = ([torch.zeros((self.maxc * 64, 4), dtype=torch.float32, device=self.stage_dev) for _ in range(world)]
+                     if rank == 0 else None)
+
+    def assemble(self, accum, stream=0):
+        if self.world <= 1:
+            return accum
+        if self.cuda:
+            self.ctx.pack_owned(self.params, accum.data_ptr(), self.packed.data_ptr(), stream)
+            send = self.packed if self.stage_dev != "cpu" else self.packed.cpu()
+        else:
+            ix = torch.from_numpy(self.index[self.rank].reshape(-1).clip(min=0))
+            self.packed[: len(ix)] = accum.view(-1, 4)[ix]
+            send = self.packed
+        dist.gather(send, self.recv if self.rank == 0 else None, dst=0)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                if self.cuda:
+                    buf = self.recv[r] if self.stage_dev != "cpu" else self.recv[r].to(accum.device)
+                    self.ctx.unpack_owned(self.params, r, buf.data_ptr(), accum.data_ptr(), stream)
+                    if self.stage_dev == "cpu":
+                        torch.cuda.synchronize()  # buf is a temporary
+                else:
+                    ix = self.index[r].reshape(-1)
+                    ok = torch.from_numpy(ix >= 0)
+                    accum.view(-1, 4)[torch.from_numpy(ix[ix >= 0])] = self.recv[r][: len(ix)][ok]
+        return accum
 
 
 def max_over_ranks(value, device):

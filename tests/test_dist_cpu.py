@@ -1,7 +1,8 @@
-"""N>1 path on CPU: two gloo ranks shard the frame by tiles exactly as bench.py's
-ranks do (rt_params.rank/world/tile), the oracle stands in for the GPU kernel, one
-SUM reduce assembles the frame on rank 0.  The assembled frame must be bit-identical
-to the single-rank frame (each pixel is non-zero on exactly one rank; adding zeros is exact)."""
+"""N>1 path on CPU: gloo ranks shard the frame by tiles exactly as bench.py's ranks do
+(rt_params.rank/world/tile), the oracle stands in for the GPU kernel, and the frame is
+assembled on rank 0 both ways: FrameAssembler (what bench.py runs: one gather of each
+rank's OWNED granules) and the reference exchange (a full-frame SUM reduce).  Either way
+the assembled frame must be bit-identical to the single-rank frame."""
 import os
 import subprocess
 import sys
@@ -19,13 +20,17 @@ WORKER = textwrap.dedent("""
     import pyrt, orc
     from pyrt import dist as rdist
     rank, world, local = rdist.init_from_env("gloo")
-    w, h, spp, tile = 48, 40, 3, int(sys.argv[3])
+    w, h, spp, tile = 45, 37, 3, int(sys.argv[3])
     scene = pyrt.Scene("cubes", w, h)
     p = pyrt.make_params(w, h, spp, seed=4, rank=rank, world=world, tile=tile)
     _, acc, st = orc.render(scene, p, math_mode=orc.MATH_DET, threads=2)
     t = torch.from_numpy(acc.copy())
     owned = int((t.abs().sum(-1) > 0).sum())
-    rdist.reduce_frame(t, dst=0)
+    g = torch.from_numpy(acc.copy())
+    rdist.FrameAssembler(None, p, rank, world, "cpu").assemble(g)   # what bench.py runs
+    rdist.reduce_frame(t, dst=0)                                    # reference exchange
+    if rank == 0:
+        assert torch.equal(g.view(torch.int32), t.view(torch.int32)), "gather and reduce disagree"
     tot = rdist.sum_over_ranks([st.rays_closest + st.rays_shadow, owned], "cpu")
     mx = rdist.max_over_ranks(float(rank), "cpu")
     if rank == 0:
@@ -47,7 +52,7 @@ def test_tile_sharded_frame_equals_single_rank(tmp_path, world, tile):
                         "--master-addr", "127.0.0.1", "--master-port", str(29600 + world * 10 + tile), str(script),
                         pyrt.ROOT, str(out), str(tile)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    w, h, spp = 48, 40, 3
+    w, h, spp = 45, 37, 3
     scene = pyrt.Scene("cubes", w, h)
     _, full, st = orc.render(scene, pyrt.make_params(w, h, spp, seed=4), math_mode=orc.MATH_DET)
     got = np.load(out)
@@ -66,3 +71,18 @@ def test_ownership_partitions_the_frame():
         owner = ((xs // tile) + (ys // tile)) % world
         counts = np.bincount(owner.ravel(), minlength=world)
         assert counts.sum() == w * h and counts.max() - counts.min() <= 0.02 * w * h / world
+
+
+def test_owned_granule_order_matches_the_library():
+    """pyrt.dist.owned_granule_index (numpy, used on CPU tensors) and rt_owned_granules (the
+    library's count, host-only) agree; the granules of all ranks partition the image."""
+    from pyrt import dist as rdist
+    for w, h, world, tile in ((45, 37, 2, 8), (1024, 1024, 8, 32), (96, 64, 3, 16), (17, 9, 5, 8)):
+        seen = np.zeros(w * h, np.int32)
+        for r in range(world):
+            p = pyrt.make_params(w, h, 1, rank=r, world=world, tile=tile)
+            ix = rdist.owned_granule_index(w, h, r, world, tile)
+            assert len(ix) == pyrt.owned_granules(p, r)
+            np.add.at(seen, ix[ix >= 0], 1)
+            assert (np.diff(ix[:, 0]) > 0).all()  # row-major granule order
+        assert (seen == 1).all()

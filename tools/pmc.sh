@@ -15,7 +15,7 @@ for set in \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum" \
   "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > $out/p$i.log 2>&1 || echo "pass $i failed" >> $out/fail.log
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --no-cpu-baseline --no-pmc --steps 1 --warmup 0 "$@" > $out/p$i.log 2>&1 || echo "pass $i failed" >> $out/fail.log
 done
 python3 - "$out" <<'PY'
 import sys,glob,csv,collections
@@ -23,9 +23,13 @@ out=sys.argv[1]
 agg=collections.OrderedDict()
 for f in sorted(glob.glob(out+"/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "k_render<" not in r["Kernel_Name"]: continue
-        if r["Kernel_Name"].split("k_render<")[1].split(">")[0].split(", ")[3] == "true": continue  # the STATS build
-        key=(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
+        n=r["Kernel_Name"]
+        if "k_render_persist<" in n:
+            if n.split("k_render_persist<")[1].split(">")[0].split(", ")[0] == "true": continue  # the STATS build
+        elif "k_render<" in n:
+            if n.split("k_render<")[1].split(">")[0].split(", ")[3] == "true": continue
+        else: continue
+        key=(n.split("(")[0][-40:], r["Counter_Name"])
         agg.setdefault(key,[]).append(float(r["Counter_Value"]))
 with open(out+"/summary.txt","w") as fo:
     for (k,c),v in agg.items():

@@ -8,7 +8,7 @@ wl=$1; shift
 out=gpurun_out/traffic_$wl
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --workload $wl --no-cpu-baseline --steps 1 --warmup 0 "$@" > $out/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --workload $wl --no-cpu-baseline --no-pmc --steps 1 --warmup 0 "$@" > $out/$c.log 2>&1
 done
 python3 - "$out" "$wl" "$@" <<'PY'
 import sys,glob,csv,json
