@@ -212,9 +212,7 @@ def cpu_baseline(ctx, scene_kind, mode, device):
 def build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, rank, world):
     accel = pyrt.ACCEL_BRUTE if args.accel == "brute" else pyrt.ACCEL_BVH
     if nph:
-        pos, dr, wt = ctx.emit_photons(nph, seed=1)
-        kp, kd_, _ = pyrt.kd_order(pos, dr, wt)
-        ctx.set_photons(kp, kd_)
+        ctx.build_photon_map(nph, seed=1)  # emission + kd order on the device
     return pyrt.make_params(w, h, spp, mode=mode, seed=1, accel=accel, rank=rank, world=world, tile=32,
                             use_photons=1 if nph else 0, k=k, photons_requested=nph, lanes_per_pixel=args.lpp)
 

@@ -156,6 +156,23 @@ int rt_set_photons(rt_ctx* ctx, const float* pos3, const float* dir3, uint32_t n
 int rt_emit_photons(rt_ctx* ctx, uint32_t n_requested, uint32_t seed, float* pos3,
                     float* dir3, float* weight, uint32_t* n_out);
 
+/* The whole photon map on the device (Renderer.cpp:209-213: PhotonMap + kdtree built inside
+ * render()): emission (the rt_emit_photons kernel), stable compaction of the stored
+ * particles, and the kd-tree order — the reference's recursive std::nth_element
+ * (kdtree.h:60-69) restated for the GPU so that the array order, ties included, is the
+ * library's (csrc/kd_build.hip) — installed as the context's photon map.  Photons never
+ * visit the host; ms_out (optional, [2]) = {emission + compaction, kd order} device ms. */
+int rt_build_photon_map(rt_ctx* ctx, uint32_t n_requested, uint32_t seed, uint32_t* n_stored,
+                        double* ms_out);
+/* The context's photon map in tree order (inspection / PhotonMap::saveToPCD). */
+int rt_get_photons(rt_ctx* ctx, float* pos3, float* dir3, float* weight, uint32_t cap,
+                   uint32_t* n_out);
+/* Test hook: the device kd order of n host-given positions; perm_out[i] = input index of
+ * tree slot i.  depth_limit < 0: std::nth_element's 2*lg(n); >= 0 forces the heap-select
+ * path early (parity of __heap_select itself). */
+int rt_test_kd_order(int32_t device, const float* pos3, uint32_t n, int32_t depth_limit,
+                     uint32_t* perm_out, double* ms_out);
+
 /* Whole frame on host buffers: background_rgb / out_rgb are [h][w][3] floats.
  * accum_out (optional, [h][w][4]) receives {sum r,g,b, primary-hit count}. */
 int rt_render(rt_ctx* ctx, const rt_params* p, const float* background_rgb,

@@ -798,6 +798,36 @@ int orc_kd_build(float* photons7, uint32_t n) {
   return RT_OK;
 }
 
+// kdtree::make_tree with std::__introselect called directly and an explicit depth limit
+// (< 0: nth_element's own 2*lg(n)): the checker for the GPU build's heap-select path.
+// perm_out[i] = input index of tree slot i.
+int orc_kd_order_depth(const float* pos3, uint32_t n, int32_t depth_limit, uint32_t* perm_out) {
+  struct Item {
+    float p[3];
+    uint32_t src;
+  };
+  std::vector<Item> items(n);
+  for (uint32_t i = 0; i < n; i++) memcpy(items[i].p, pos3 + 3 * (size_t)i, 12), items[i].src = i;
+  struct Range {
+    size_t b, e, axis;
+  };
+  std::vector<Range> todo{{0, n, 0}};
+  while (!todo.empty()) {
+    const Range r = todo.back();
+    todo.pop_back();
+    if (r.e <= r.b) continue;
+    const size_t mid = r.b + (r.e - r.b) / 2, ax = r.axis;
+    auto cmp = [ax](const Item& a, const Item& b) { return a.p[ax] < b.p[ax]; };
+    const long lim = depth_limit < 0 ? std::__lg((long)(r.e - r.b)) * 2 : depth_limit;
+    std::__introselect(items.begin() + r.b, items.begin() + mid, items.begin() + r.e, lim,
+                       __gnu_cxx::__ops::__iter_comp_iter(cmp));
+    todo.push_back({mid + 1, r.e, (ax + 1) % 3});
+    todo.push_back({r.b, mid, (ax + 1) % 3});
+  }
+  for (uint32_t i = 0; i < n; i++) perm_out[i] = items[i].src;
+  return RT_OK;
+}
+
 int orc_knn(const float* photons7_kd, uint32_t n, const float* query3, uint32_t nq, uint32_t k,
             uint32_t* idx_out, float* dist_out, uint32_t* visited_out) {
   KdTree t;

@@ -709,6 +709,126 @@ int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint
   return RT_OK;
 }
 
+// ------------------------------------------------------------------ photon map on the device
+int rt_build_photon_map(rt_ctx* c, uint32_t n_requested, uint32_t seed, uint32_t* n_stored, double* ms_out) {
+  if (!c || !n_stored) return fail(RT_ERR_INVALID, "ctx/n_stored is null");
+  *n_stored = 0;
+  HIP_TRY(hipSetDevice(c->device));
+  // forget the old map first (see rt_set_photons)
+  c->S.phPos = c->S.phDir = nullptr, c->S.n_photons = 0;
+  if (c->phPos) (void)hipFree(c->phPos);
+  if (c->phDir) (void)hipFree(c->phDir);
+  c->phPos = c->phDir = nullptr;
+  if (n_requested == 0 || c->S.n_lights == 0) return RT_OK;
+  const float lightPdf = 1.f / static_cast<float>(c->S.n_lights);  // PhotonMap.h:19-20
+  const uint32_t perLight = static_cast<uint32_t>(static_cast<int>(static_cast<float>(static_cast<int>(n_requested)) * lightPdf));
+  const uint32_t n = perLight * c->S.n_lights;
+  if (n == 0) return RT_OK;
+  float4 *slotPos = nullptr, *slotDir = nullptr, *items = nullptr, *phPos = nullptr, *phDir = nullptr;
+  uint32_t* dCount = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  auto cleanup = [&]() {
+    for (void* p : {(void*)slotPos, (void*)slotDir, (void*)items, (void*)dCount})
+      if (p) (void)hipFree(p);
+    for (hipEvent_t e : ev)
+      if (e) (void)hipEventDestroy(e);
+  };
+  hipError_t he = hipMalloc(reinterpret_cast<void**>(&slotPos), n * sizeof(float4));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&slotDir), n * sizeof(float4));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&items), n * sizeof(float4));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&dCount), sizeof(uint32_t));
+  for (auto& e : ev)
+    if (he == hipSuccess) he = hipEventCreate(&e);
+  if (he == hipSuccess) he = hipEventRecord(ev[0], nullptr);
+  if (he == hipSuccess) he = rtk::launch_emit(c->S, perLight, seed, slotPos, slotDir, c->dCounters, nullptr);
+  if (he == hipSuccess) he = rtk::launch_photon_compact(slotPos, n, items, dCount, nullptr);
+  if (he == hipSuccess) he = hipEventRecord(ev[1], nullptr);
+  uint32_t m = 0;
+  if (he == hipSuccess) he = hipMemcpy(&m, dCount, sizeof m, hipMemcpyDeviceToHost);  // (the count only)
+  if (he == hipSuccess && m) {
+    he = rtk::launch_kd_build(items, m, -1, nullptr);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phPos), m * sizeof(float4));
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phDir), m * sizeof(float4));
+    if (he == hipSuccess) he = rtk::launch_photon_gather(items, slotDir, m, phPos, phDir, nullptr, nullptr);
+  }
+  if (he == hipSuccess) he = hipEventRecord(ev[2], nullptr);
+  if (he == hipSuccess) he = hipDeviceSynchronize();
+  if (he == hipSuccess && ms_out) {
+    float a = 0.f, b = 0.f;
+    (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+    ms_out[0] = a, ms_out[1] = b;  // emission + compaction, kd order + gather
+  }
+  cleanup();
+  if (he != hipSuccess) {
+    if (phPos) (void)hipFree(phPos);
+    if (phDir) (void)hipFree(phDir);
+    return fail(RT_ERR_HIP, "photon map build failed: %s", hipGetErrorString(he));
+  }
+  c->phPos = phPos, c->phDir = phDir;
+  c->S.phPos = phPos, c->S.phDir = phDir, c->S.n_photons = m;
+  *n_stored = m;
+  return RT_OK;
+}
+
+int rt_get_photons(rt_ctx* c, float* pos3, float* dir3, float* weight, uint32_t cap, uint32_t* n_out) {
+  if (!c || !n_out) return fail(RT_ERR_INVALID, "ctx/n_out is null");
+  const uint32_t n = c->S.n_photons;
+  *n_out = n;
+  if (n == 0) return RT_OK;
+  if (cap < n) return fail(RT_ERR_INVALID, "capacity %u < %u photons", cap, n);
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<float4> p(n), d(n);
+  HIP_TRY(hipMemcpy(p.data(), c->phPos, n * sizeof(float4), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(d.data(), c->phDir, n * sizeof(float4), hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; ++i) {
+    if (pos3) pos3[3 * (size_t)i] = p[i].x, pos3[3 * (size_t)i + 1] = p[i].y, pos3[3 * (size_t)i + 2] = p[i].z;
+    if (dir3) dir3[3 * (size_t)i] = d[i].x, dir3[3 * (size_t)i + 1] = d[i].y, dir3[3 * (size_t)i + 2] = d[i].z;
+    if (weight) weight[i] = d[i].w;
+  }
+  return RT_OK;
+}
+
+int rt_test_kd_order(int32_t device, const float* pos3, uint32_t n, int32_t depth_limit, uint32_t* perm_out, double* ms_out) {
+  if (n && (!pos3 || !perm_out)) return fail(RT_ERR_INVALID, "null argument");
+  if (n == 0) return RT_OK;
+  int rc = select_device(device);
+  if (rc != RT_OK) return rc;
+  std::vector<float4> h(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t bits = i;
+    float f;
+    memcpy(&f, &bits, 4);
+    h[i] = make_float4(pos3[3 * (size_t)i], pos3[3 * (size_t)i + 1], pos3[3 * (size_t)i + 2], f);
+  }
+  float4 *items = nullptr, *scratch = nullptr;
+  uint32_t* dPerm = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  rc = upload(&items, h.data(), n);
+  if (rc != RT_OK) return rc;
+  hipError_t he = hipMalloc(reinterpret_cast<void**>(&scratch), n * sizeof(float4));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&dPerm), n * sizeof(uint32_t));
+  if (he == hipSuccess) he = hipEventCreate(&e0);
+  if (he == hipSuccess) he = hipEventCreate(&e1);
+  if (he == hipSuccess) he = hipEventRecord(e0, nullptr);
+  if (he == hipSuccess) he = rtk::launch_kd_build(items, n, depth_limit, nullptr);
+  if (he == hipSuccess) he = hipEventRecord(e1, nullptr);
+  if (he == hipSuccess) he = rtk::launch_photon_gather(items, nullptr, n, scratch, nullptr, dPerm, nullptr);
+  if (he == hipSuccess) he = hipMemcpy(perm_out, dPerm, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  if (he == hipSuccess && ms_out) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms;
+  }
+  (void)hipFree(items);
+  if (scratch) (void)hipFree(scratch);
+  if (dPerm) (void)hipFree(dPerm);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "kd order failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------ multi-GPU frame assembly
 int rt_owned_granules(const rt_params* p, uint32_t rank, uint32_t* n_out) {
   if (!p || !n_out) return fail(RT_ERR_INVALID, "null argument");

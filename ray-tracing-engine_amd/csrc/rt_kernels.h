@@ -77,6 +77,11 @@ hipError_t launch_knn(const DevScene& S, const float* q, uint32_t n, uint32_t k,
                       uint32_t* visited, hipStream_t stream);
 hipError_t launch_emit(const DevScene& S, uint32_t perLight, uint32_t seed, float4* outPos, float4* outDir,
                        unsigned long long* counters, hipStream_t stream);
+// photon map on the device (kd_build.hip)
+hipError_t launch_photon_compact(const float4* slots, uint32_t n, float4* items, uint32_t* count, hipStream_t stream);
+hipError_t launch_kd_build(float4* items, uint32_t n, int depthOverride, hipStream_t stream);
+hipError_t launch_photon_gather(const float4* items, const float4* slotDir, uint32_t n, float4* phPos, float4* phDir,
+                                uint32_t* perm, hipStream_t stream);
 hipError_t launch_unit(uint32_t which, const void* in, void* out, uint32_t n, hipStream_t stream);
 
 }  // namespace rtk

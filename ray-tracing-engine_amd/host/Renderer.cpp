@@ -31,24 +31,36 @@ inline void Renderer::render(Image& image) {
   // Renderer.cpp:209-213: the photon map and its kd-tree are built inside render();
   // the map is a local there (the member stays empty, so a savePhotonMap() issued
   // BEFORE render() writes an empty cloud, as in the reference).  We keep the member
-  // filled afterwards so that a later savePhotonMap() is useful.
+  // filled afterwards (in tree order) so that a later savePhotonMap() is useful.
   if (m_numPhotons > 0) {
-    PhotonMap map(ctx0, m_numPhotons, m_scene.lightsources().size());
+    // the whole map on the device(s): emission, compaction and the kd order (the
+    // reference's std::nth_element order, restated tie-exactly: csrc/kd_build.hip); every
+    // device of a group builds the same map from the same streams.  The host copy only
+    // feeds a later savePhotonMap().
+    std::cout << "Constructing a photon map with " << m_numPhotons << " photons" << std::endl;
+    if (!m_scene.lightsources().empty())
+      std::cout << "Emitting " << static_cast<int>(m_numPhotons * (1.f / m_scene.lightsources().size()))
+                << " photons per light source" << std::endl;
     std::cout << "Constructing a kd-tree for the photon map." << std::endl;
-    kdtree tree(map.list().begin(), map.list().end());
-    if (!tree.empty()) {
-      std::vector<float> pos(3 * tree.size()), dir(3 * tree.size());
-      for (size_t i = 0; i < tree.size(); ++i)
-        for (int c = 0; c < 3; ++c)
-          pos[3 * i + c] = tree.nodes()[i].position()[c], dir[3 * i + c] = tree.nodes()[i].incomeDirection()[c];
-      if (multi)
-        GpuSession::check(rt_group_set_photons(many->group(), pos.data(), dir.data(), static_cast<uint32_t>(tree.size())),
-                          "rt_group_set_photons");
-      else
-        GpuSession::check(rt_set_photons(ctx0, pos.data(), dir.data(), static_cast<uint32_t>(tree.size())), "rt_set_photons");
+    uint32_t stored = 0;
+    const uint32_t ranks = multi ? rt_group_size(many->group()) : 1u;
+    for (uint32_t r = 0; r < ranks; ++r) {
+      rt_ctx* cr = multi ? rt_group_ctx(many->group(), r) : ctx0;
+      GpuSession::check(rt_build_photon_map(cr, static_cast<uint32_t>(m_numPhotons), GpuSettings::get().seed, &stored, nullptr),
+                        "rt_build_photon_map");
+    }
+    std::cout << stored << " photons stored" << std::endl;
+    if (stored) {
+      std::vector<float> pos(3 * static_cast<size_t>(stored)), dir(pos.size()), wt(stored);
+      uint32_t n = 0;
+      GpuSession::check(rt_get_photons(ctx0, pos.data(), dir.data(), wt.data(), stored, &n), "rt_get_photons");
+      PhotonMap map;
+      for (uint32_t i = 0; i < n; ++i)
+        map.list().push_back(Particle(Vec3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]),
+                                      Vec3f(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), wt[i]));
+      m_photonMap = map;
       p.use_photons = 1, p.k = static_cast<uint32_t>(m_k), p.photons_requested = static_cast<uint32_t>(m_numPhotons);
     }
-    m_photonMap = map;
   }
 
   Image result(w, h);

@@ -87,7 +87,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("mesh", "<u4"), ("tri", "<u4"), ("vtx", "
 AMD_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_photons", "rt_emit_photons",
                "rt_render", "rt_render_passes", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
                "rt_bvh_export", "rt_bvh_build_host", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
-               "rt_owned_granules", "rt_pack_owned_device", "rt_unpack_owned_device", "rt_group_create", "rt_group_destroy",
+               "rt_build_photon_map", "rt_get_photons", "rt_test_kd_order", "rt_owned_granules", "rt_pack_owned_device", "rt_unpack_owned_device", "rt_group_create", "rt_group_destroy",
                "rt_group_size", "rt_group_uses_rccl", "rt_group_ctx", "rt_group_set_photons", "rt_group_render"]
 HOST_SYMBOLS = ["rt_host_scene_build", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error",
                 "rt_host_fill_background", "rt_host_save_ppm", "rt_host_kd_order"]
@@ -138,6 +138,9 @@ def amd():
         L.rt_profile_reset.argtypes = [C.c_void_p]
         L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.rt_test_unit.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.rt_build_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        L.rt_get_photons.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.rt_test_kd_order.argtypes = [C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
         L.rt_owned_granules.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_uint32)]
         L.rt_pack_owned_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_unpack_owned_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -293,6 +296,21 @@ class Context:
         _check(amd().rt_emit_photons(self._h, n_requested, seed, _ptr(pos), _ptr(dir_), _ptr(w), C.byref(n)))
         return pos[:n.value].copy(), dir_[:n.value].copy(), w[:n.value].copy()
 
+    def build_photon_map(self, n_requested, seed=1):
+        """Emission + compaction + kd order on the device; returns (n_stored, [emit_ms, kd_ms])."""
+        n = C.c_uint32()
+        ms = (C.c_double * 2)()
+        _check(amd().rt_build_photon_map(self._h, n_requested, seed, C.byref(n), ms))
+        return n.value, [ms[0], ms[1]]
+
+    def get_photons(self, cap):
+        pos = np.zeros((max(cap, 1), 3), np.float32)
+        dir_ = np.zeros_like(pos)
+        w = np.zeros(max(cap, 1), np.float32)
+        n = C.c_uint32()
+        _check(amd().rt_get_photons(self._h, _ptr(pos), _ptr(dir_), _ptr(w), cap, C.byref(n)))
+        return pos[:n.value].copy(), dir_[:n.value].copy(), w[:n.value].copy()
+
     def render(self, params, bg=None, want_accum=True):
         w, h = params.width, params.height
         out = np.empty((h, w, 3), np.float32) if bg is not None else None
@@ -352,6 +370,15 @@ class Context:
         vis = np.zeros(len(q), np.uint32)
         _check(amd().rt_knn(self._h, _ptr(q), len(q), k, _ptr(idx), _ptr(dist), _ptr(vis)))
         return idx, dist, vis
+
+
+def kd_order_device(pos, depth_limit=-1, device=0):
+    """rt_test_kd_order: permutation (tree slot -> input index) built on the GPU, and its ms."""
+    pos = np.ascontiguousarray(pos, np.float32)
+    perm = np.zeros(len(pos), np.uint32)
+    ms = C.c_double()
+    _check(amd().rt_test_kd_order(device, _ptr(pos), len(pos), depth_limit, _ptr(perm), C.byref(ms)))
+    return perm, ms.value
 
 
 def owned_granules(params, rank):

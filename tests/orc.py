@@ -34,6 +34,7 @@ def lib():
                                        C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                        C.POINTER(C.c_uint64)]
         L.orc_kd_build.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_kd_order_depth.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
         L.orc_knn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                               C.c_void_p]
         L.orc_ppm_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
@@ -126,6 +127,15 @@ def kd_build(photons7):
     a = np.ascontiguousarray(photons7, np.float32).copy()
     lib().orc_kd_build(_p(a), len(a))
     return a
+
+
+def kd_order_depth(pos, depth_limit=-1):
+    """Tree-slot -> input-index permutation of kdtree::make_tree, with std::__introselect's
+    depth limit forced (>= 0) or the library's own (< 0)."""
+    pos = np.ascontiguousarray(pos, np.float32)
+    perm = np.zeros(len(pos), np.uint32)
+    lib().orc_kd_order_depth(_p(pos), len(pos), depth_limit, _p(perm))
+    return perm
 
 
 def knn(photons7_kd, queries, k):
