@@ -84,8 +84,12 @@ enum { RT_TRACE_CLOSEST = 0, RT_TRACE_ANY = 1 };
 typedef struct rt_options {
   int32_t device;          /* HIP device ordinal                              */
   uint32_t bvh_leaf_max;   /* 0 = default (2), max 8                          */
-  uint32_t reserved[6];
+  uint32_t bvh_builder;    /* RT_BVH_HOST (SAH, host threads) | RT_BVH_DEVICE (Morton-
+                              order SAH on the GPU, csrc/bvh_gpu.hip); the environment
+                              variable RT_BVH_GPU=1 selects the device builder too      */
+  uint32_t reserved[5];
 } rt_options;
+enum { RT_BVH_HOST = 0, RT_BVH_DEVICE = 1 };
 
 typedef struct rt_params {
   uint32_t width, height;
@@ -138,7 +142,9 @@ typedef struct rt_hit {
 typedef struct rt_bvh_info {
   uint32_t n_nodes, n_tri_records, max_depth, leaf_max;
   float pad;           /* absolute box padding used                             */
-  uint32_t reserved[3];
+  float build_ms;      /* wall time of the build inside rt_create                */
+  uint32_t builder;    /* RT_BVH_HOST / RT_BVH_DEVICE                            */
+  uint32_t reserved[1];
 } rt_bvh_info;
 
 typedef struct rt_ctx rt_ctx;

@@ -234,41 +234,6 @@ struct Builder {
   }
 };
 
-// float -> binary16 with directed rounding (toward -inf when up == false, toward
-// +inf when up == true).  Inputs are finite and |x| <= 32768 by construction.
-uint16_t toHalfDirected(float x, bool up) {
-  uint32_t u;
-  std::memcpy(&u, &x, 4);
-  const uint32_t sign = u >> 31;
-  const float ax = std::fabs(x);
-  // away-from-zero rounding of the magnitude is needed iff the direction matches the sign
-  const bool away = (up && !sign) || (!up && sign);
-  uint32_t h;
-  if (ax == 0.f) {
-    h = 0;
-  } else if (ax < 6.103515625e-05f) {  // below the smallest normal half: fixed-point with 2^-24 steps
-    const float q = ax * 16777216.f;   // exact
-    uint32_t m = static_cast<uint32_t>(q);
-    if (away && static_cast<float>(m) < q) ++m;
-    h = m;                             // m == 1024 carries into the smallest normal, as it should
-  } else {
-    uint32_t au = u & 0x7fffffffu;
-    const uint32_t lost = au & 0x1fffu;  // 13 mantissa bits do not fit
-    au >>= 13;
-    if (away && lost) ++au;              // a carry walks into the exponent, as it should
-    h = au - ((127u - 15u) << 10);
-  }
-  return static_cast<uint16_t>((sign << 15) | h);
-}
-
-float halfToFloat(uint16_t hv) {
-  const uint32_t sign = (hv >> 15) & 1u, e = (hv >> 10) & 31u, m = hv & 1023u;
-  float v;
-  if (e == 0) v = static_cast<float>(m) * 5.9604644775390625e-08f;  // 2^-24
-  else v = std::ldexp(static_cast<float>(m | 1024u), static_cast<int>(e) - 25);
-  return sign ? -v : v;
-}
-
 TriRec makeRec(const rt_scene_desc& sc, uint32_t t, uint32_t mesh) {
   TriRec r;
   const float* p0 = sc.vertex_pos + 3 * static_cast<size_t>(sc.tri_vtx[3 * static_cast<size_t>(t) + 0]);
@@ -404,6 +369,82 @@ struct Rotator {
 };
 
 }  // namespace
+
+// float -> binary16 with directed rounding (toward -inf when up == false, toward
+// +inf when up == true).  Inputs are finite and |x| <= 32768 by construction.
+uint16_t toHalfDirected(float x, bool up) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  const uint32_t sign = u >> 31;
+  const float ax = std::fabs(x);
+  // away-from-zero rounding of the magnitude is needed iff the direction matches the sign
+  const bool away = (up && !sign) || (!up && sign);
+  uint32_t h;
+  if (ax == 0.f) {
+    h = 0;
+  } else if (ax < 6.103515625e-05f) {  // below the smallest normal half: fixed-point with 2^-24 steps
+    const float q = ax * 16777216.f;   // exact
+    uint32_t m = static_cast<uint32_t>(q);
+    if (away && static_cast<float>(m) < q) ++m;
+    h = m;                             // m == 1024 carries into the smallest normal, as it should
+  } else {
+    uint32_t au = u & 0x7fffffffu;
+    const uint32_t lost = au & 0x1fffu;  // 13 mantissa bits do not fit
+    au >>= 13;
+    if (away && lost) ++au;              // a carry walks into the exponent, as it should
+    h = au - ((127u - 15u) << 10);
+  }
+  return static_cast<uint16_t>((sign << 15) | h);
+}
+
+float halfToFloat(uint16_t hv) {
+  const uint32_t sign = (hv >> 15) & 1u, e = (hv >> 10) & 31u, m = hv & 1023u;
+  float v;
+  if (e == 0) v = static_cast<float>(m) * 5.9604644775390625e-08f;  // 2^-24
+  else v = std::ldexp(static_cast<float>(m | 1024u), static_cast<int>(e) - 25);
+  return sign ? -v : v;
+}
+
+ScenePlan planScene(const rt_scene_desc& sc, uint32_t leafMax) {
+  ScenePlan P;
+  if (leafMax == 0) leafMax = 2;
+  if (leafMax > 8) leafMax = 8;
+  P.leafMax = leafMax;
+  if (sc.n_triangles == 0 || sc.n_triangles >= (1u << 28)) throw std::runtime_error("triangle count out of range");
+  if (sc.mesh_tri_begin[sc.n_meshes] != sc.n_triangles || sc.mesh_vtx_begin[sc.n_meshes] != sc.n_vertices)
+    throw std::runtime_error("mesh offset tables inconsistent with counts");
+  for (uint32_t m = 0; m < sc.n_meshes; ++m) {
+    if (sc.mesh_tri_begin[m] > sc.mesh_tri_begin[m + 1]) throw std::runtime_error("mesh_tri_begin not monotone");
+    for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; ++t)
+      for (int k = 0; k < 3; ++k) {
+        const uint32_t v = sc.tri_vtx[3 * static_cast<size_t>(t) + k];
+        if (v < sc.mesh_vtx_begin[m] || v >= sc.mesh_vtx_begin[m + 1])
+          throw std::runtime_error("triangle references a vertex outside its mesh");
+        const float* q = sc.vertex_pos + 3 * static_cast<size_t>(v);
+        for (int a = 0; a < 3; ++a) {
+          if (!std::isfinite(q[a])) throw std::runtime_error("non-finite vertex position");
+          P.maxAbs = std::max(P.maxAbs, std::fabs(q[a]));
+        }
+      }
+  }
+  int levels = 0;
+  for (uint32_t n = sc.n_triangles; n > leafMax; n = (n + 1) / 2) ++levels;
+  const char* slack = getenv("RT_BVH_SLACK");
+  P.depthCap = std::min(kMaxDepth - 1, levels + (slack ? atoi(slack) : (levels >= 19 ? 2 : 3)));
+  float padRef = std::max(1.f, P.maxAbs);
+  for (int a = 0; a < 3; ++a)
+    if (std::isfinite(sc.camera.position[a])) padRef = std::max(padRef, std::fabs(sc.camera.position[a]));
+  for (uint32_t l = 0; l < sc.n_lights; ++l)
+    for (int a = 0; a < 3; ++a)
+      if (std::isfinite(sc.lights[l].position[a])) padRef = std::max(padRef, std::fabs(sc.lights[l].position[a]));
+  P.pad = 6e-5f * padRef;
+  P.originBound = 16.f * padRef;
+  int e = 0;
+  std::frexp(32768.f / std::max(P.maxAbs + P.pad, 1e-30f), &e);
+  P.boxScale = std::ldexp(1.f, std::min(std::max(e - 1, -100), 100));
+  return P;
+}
+
 
 // Final node numbering: the kTop nodes a ray is most likely to visit first — taken
 // greedily by box surface area from the root, so the set is closed under "parent of" and

@@ -70,6 +70,18 @@ struct Built {
   float originBound = 0.f;      // ray origins with a larger |coordinate| are outside the padding analysis
 };
 
+// What both builders (host: build(); device: csrc/bvh_gpu.hip) derive from the scene
+// before touching a triangle: validation (throws std::runtime_error on an inconsistent
+// description), the leaf size, the depth cap, the box padding and the f16 plane scale.
+struct ScenePlan {
+  uint32_t leafMax = 2;
+  int depthCap = kMaxDepth - 1;  // deepest leaf level the tree may use (root = 0)
+  float maxAbs = 0.f, pad = 0.f, originBound = 0.f, boxScale = 1.f;
+};
+ScenePlan planScene(const rt_scene_desc& scene, uint32_t leafMax);
+uint16_t toHalfDirected(float x, bool up);
+float halfToFloat(uint16_t h);
+
 // Throws std::runtime_error on an inconsistent scene description.
 // threads: builder threads (0 = one per hardware thread, at most 16); the result does not
 // depend on it.

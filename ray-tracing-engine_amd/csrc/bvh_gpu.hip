@@ -1,0 +1,424 @@
+// bvh_gpu.hip — the scene BVH built on the device.
+//
+// The reference has no usable BVH (source/BVH.h, AABB.cpp: dead code), so
+// like the host builder (bvh_build.cpp) this is our own design; it emits the SAME arrays
+// the traversal kernels read — 32-B binary16-packed nodes holding both child boxes, 48-B
+// triangle records in leaf order, leaves of <= leafMax triangles, depth <= the plan's cap —
+// so every exactness test runs unchanged on a device-built tree (RT_BVH_GPU=1).
+//
+//   1. per-triangle boxes + centroids, centroid bounds (one pass, ordered-int atomics);
+//   2. sort key = 2-bit SIZE CLASS (triangles whose box spans > 1/4, 1/16, 1/64 of the scene
+//      extent come first: a wall quad must not sit in the middle of a mesh's Morton range,
+//      where every range box containing it would be the whole room) + 60-bit Morton code of
+//      the centroid; radix sort (rocPRIM) of (key, triangle); equal keys keep ascending
+//      triangle order (stable sort): deterministic;
+//   3. a min/max segment tree over the sorted triangle boxes: the box of ANY contiguous
+//      range of the Morton order in ~2 log n steps;
+//   4. top-down, one launch set per tree level, one WAVE per node: the 64 lanes evaluate
+//      the SAH cost (area x ceil(n / leafMax), the host builder's) of up to 64 split
+//      positions of the node's Morton range — every position for ranges of <= 65
+//      triangles, and always the positions where the size class changes — restricted to
+//      splits whose sides still fit the remaining depth budget, and a wave-min picks the
+//      cheapest (lowest position on ties);
+//   5. children are numbered by an exclusive scan over the level (breadth-first node
+//      order: the top of the tree is a prefix of the array, as the LDS-resident top wants),
+//      nodes are written packed with the plan's padding and plane scale.
+// Quality: contiguous Morton ranges are a subset of the partitions full SAH considers;
+// measured nodes/ray vs the host SAH tree are in DESIGN.md.  Cost: a few ms for 1 M triangles.
+#include <hip/hip_runtime.h>
+
+#include <cstring>  // (rocPRIM's headers use memset without including it)
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "bvh_build.h"
+#include "rt_kernels.h"
+
+namespace rtk {
+namespace {
+
+struct WorkItem {
+  uint32_t b, e;  // Morton-order range
+};
+
+__device__ __forceinline__ int fkey(float f) {  // order-preserving float -> int
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float funkey(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void k_init_bounds(int* cb) {
+  if (threadIdx.x < 3) cb[threadIdx.x] = 0x7fffffff;        // min
+  else if (threadIdx.x < 6) cb[threadIdx.x] = (int)0x80000000;  // max
+}
+
+// triangle boxes (float4 lo, hi) in REFERENCE order, centroid bounds
+__global__ void k_tri_boxes(const float* __restrict__ vpos, const uint4* __restrict__ triShade, uint32_t n,
+                            float4* __restrict__ lo, float4* __restrict__ hi, int* __restrict__ cb) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  float c[3] = {0.f, 0.f, 0.f};
+  const bool on = t < n;
+  if (on) {
+    const uint4 tv = triShade[t];
+    float l[3], h[3];
+    for (int a = 0; a < 3; ++a) {
+      const float p0 = vpos[3 * (size_t)tv.x + a], p1 = vpos[3 * (size_t)tv.y + a], p2 = vpos[3 * (size_t)tv.z + a];
+      l[a] = fminf(p0, fminf(p1, p2)), h[a] = fmaxf(p0, fmaxf(p1, p2));
+      c[a] = 0.5f * l[a] + 0.5f * h[a];
+    }
+    lo[t] = make_float4(l[0], l[1], l[2], 0.f), hi[t] = make_float4(h[0], h[1], h[2], 0.f);
+  }
+  for (int a = 0; a < 3; ++a) {
+    int mn = on ? fkey(c[a]) : 0x7fffffff, mx = on ? fkey(c[a]) : (int)0x80000000;
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = min(mn, __shfl_xor(mn, off, 64));
+      mx = max(mx, __shfl_xor(mx, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) atomicMin(&cb[a], mn), atomicMax(&cb[3 + a], mx);
+  }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // 21 bits -> every third bit
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ void k_morton(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n, const int* __restrict__ cb,
+                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float4 l = lo[t], h = hi[t];
+  const float c[3] = {0.5f * l.x + 0.5f * h.x, 0.5f * l.y + 0.5f * h.y, 0.5f * l.z + 0.5f * h.z};
+  const float d[3] = {h.x - l.x, h.y - l.y, h.z - l.z};
+  uint64_t code = 0;
+  float sceneExt = 0.f, triExt = 0.f;
+  for (int a = 0; a < 3; ++a) {
+    const float mn = funkey(cb[a]), mx = funkey(cb[3 + a]);
+    const float ext = mx - mn;
+    sceneExt = fmaxf(sceneExt, ext), triExt = fmaxf(triExt, d[a]);
+    float u = ext > 0.f ? (c[a] - mn) / ext : 0.f;
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    const uint32_t q = (uint32_t)fminf(u * 1048576.f, 1048575.f);  // 20 bits per axis
+    code |= spread21(q) << (2 - a);
+  }
+  // size class: 0 = spans more than a quarter of the scene ... 3 = the small rest
+  const float rel = sceneExt > 0.f ? triExt / sceneExt : 0.f;
+  const uint64_t cls = rel > 0.25f ? 0u : rel > 0.0625f ? 1u : rel > 0.015625f ? 2u : 3u;
+  keys[t] = (cls << 60) | code, vals[t] = t;
+}
+
+// segment tree over the sorted triangle boxes: seg[N2 + i] = box of sorted triangle i
+__global__ void k_seg_leaves(const float4* __restrict__ lo, const float4* __restrict__ hi, const uint32_t* __restrict__ order,
+                             uint32_t n, uint32_t N2, float4* __restrict__ segLo, float4* __restrict__ segHi) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N2) return;
+  const float inf = __int_as_float(0x7f800000);
+  segLo[N2 + i] = i < n ? lo[order[i]] : make_float4(inf, inf, inf, 0.f);
+  segHi[N2 + i] = i < n ? hi[order[i]] : make_float4(-inf, -inf, -inf, 0.f);
+}
+__global__ void k_seg_level(uint32_t first, uint32_t count, float4* __restrict__ segLo, float4* __restrict__ segHi) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t j = first + i;
+  const float4 a = segLo[2 * j], b = segLo[2 * j + 1], c = segHi[2 * j], d = segHi[2 * j + 1];
+  segLo[j] = make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), 0.f);
+  segHi[j] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0.f);
+}
+
+struct Box3 {
+  float lx, ly, lz, hx, hy, hz;
+};
+__device__ __forceinline__ Box3 range_box(const float4* __restrict__ segLo, const float4* __restrict__ segHi, uint32_t N2,
+                                          uint32_t b, uint32_t e) {
+  const float inf = __int_as_float(0x7f800000);
+  Box3 r{inf, inf, inf, -inf, -inf, -inf};
+  auto eat = [&](uint32_t j) {
+    const float4 l = segLo[j], h = segHi[j];
+    r.lx = fminf(r.lx, l.x), r.ly = fminf(r.ly, l.y), r.lz = fminf(r.lz, l.z);
+    r.hx = fmaxf(r.hx, h.x), r.hy = fmaxf(r.hy, h.y), r.hz = fmaxf(r.hz, h.z);
+  };
+  for (uint32_t l = b + N2, rr = e + N2; l < rr; l >>= 1, rr >>= 1) {
+    if (l & 1u) eat(l++);
+    if (rr & 1u) eat(--rr);
+  }
+  return r;
+}
+__device__ __forceinline__ float half_area(const Box3& b) {
+  const float dx = b.hx - b.lx, dy = b.hy - b.ly, dz = b.hz - b.lz;
+  return dx < 0.f ? 0.f : dx * dy + dy * dz + dz * dx;
+}
+
+// float -> binary16 bits with directed rounding (bvh_build.cpp toHalfDirected, same bits)
+__device__ __forceinline__ uint32_t half_directed(float x, bool up) {
+  const uint32_t u = __float_as_uint(x);
+  const uint32_t sign = u >> 31;
+  const float ax = fabsf(x);
+  const bool away = (up && !sign) || (!up && sign);
+  uint32_t h;
+  if (ax == 0.f) {
+    h = 0;
+  } else if (ax < 6.103515625e-05f) {
+    const float q = ax * 16777216.f;
+    uint32_t m = (uint32_t)q;
+    if (away && (float)m < q) ++m;
+    h = m;
+  } else {
+    uint32_t au = u & 0x7fffffffu;
+    const uint32_t lost = au & 0x1fffu;
+    au >>= 13;
+    if (away && lost) ++au;
+    h = au - ((127u - 15u) << 10);
+  }
+  return (sign << 15) | h;
+}
+
+// One wave per node of this level: choose the split, count the inner children.
+__global__ __launch_bounds__(256) void k_level_split(const WorkItem* __restrict__ items, uint32_t count, uint32_t depth, int depthCap,
+                                                     uint32_t leafMax, const float4* __restrict__ segLo,
+                                                     const float4* __restrict__ segHi, uint32_t N2, const uint64_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ splitPos, uint32_t* __restrict__ innerCnt) {
+  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (w >= count) return;
+  const uint32_t b = items[w].b, e = items[w].e, n = e - b;
+  // a child at depth + 1 can hold at most leafMax << (depthCap - depth - 1) triangles
+  const int rem = depthCap - (int)depth - 1;
+  const uint64_t maxSide = rem >= 31 ? ~0ull : (uint64_t)leafMax << (rem < 0 ? 0 : rem);
+  const uint32_t kmin = (uint64_t)n > maxSide ? (uint32_t)(e - maxSide) : b + 1u;
+  const uint32_t kmax = (uint64_t)n > maxSide ? (uint32_t)(b + maxSide) : e - 1u;
+  const uint32_t kminC = kmin < b + 1u ? b + 1u : kmin, kmaxC = kmax > e - 1u ? e - 1u : kmax;
+  float cost = __int_as_float(0x7f800000);
+  uint32_t k = b + n / 2u;
+  auto sah = [&](uint32_t kk) {
+    const Box3 L = range_box(segLo, segHi, N2, b, kk), R = range_box(segLo, segHi, N2, kk, e);
+    const float nl = (float)((kk - b + leafMax - 1u) / leafMax), nr = (float)((e - kk + leafMax - 1u) / leafMax);
+    float c = half_area(L) * nl + half_area(R) * nr;
+    return c == c ? c : 3.0e38f;  // (NaN-proof: a degenerate box product)
+  };
+  auto lower_bound = [&](uint64_t key) {
+    uint32_t lo_ = b, hi_ = e;
+    while (lo_ < hi_) {
+      const uint32_t mid = lo_ + (hi_ - lo_) / 2u;
+      if (keys[mid] < key) lo_ = mid + 1u;
+      else hi_ = mid;
+    }
+    return lo_;
+  };
+  if (kminC <= kmaxC) {
+    const uint32_t span = kmaxC - kminC;  // candidates kminC .. kmaxC
+    if (span < 64u) {
+      // every position
+      if (lane <= span) k = kminC + lane, cost = sah(k);
+    } else {
+      // (a) evenly spaced positions; the last three lanes take the positions where the size
+      // class changes inside the range
+      k = kminC + (uint32_t)(((uint64_t)lane * span) / 63u);
+      if (lane >= 61u) {
+        const uint32_t kb = lower_bound((uint64_t)(lane - 60u) << 60);  // first key of class 1, 2, 3
+        if (kb >= kminC && kb <= kmaxC) k = kb;
+      }
+      cost = sah(k);
+      // (b) Morton-cell boundaries: a contiguous range of the curve that holds a sliver of the
+      // neighbouring cell has that cell's extent in its box, so the cuts that matter are the
+      // cell boundaries — the 63 places where the 6 key bits below the range's common prefix
+      // change (two octree levels; lane 32 is the classic LBVH split)
+      const uint64_t kf = keys[b], kl = keys[e - 1u];
+      if (kf != kl && lane >= 1u) {
+        const int hb = 63 - __clzll((long long)(kf ^ kl));  // highest differing bit
+        const int sh = hb >= 5 ? hb - 5 : 0;
+        const uint64_t prefix = hb >= 63 ? 0ull : (kf >> (hb + 1)) << (hb + 1);
+        const uint64_t sub = (uint64_t)lane << sh;
+        if (hb >= 5 || lane < (1u << (hb + 1))) {
+          const uint32_t kb = lower_bound(prefix | sub);
+          if (kb >= kminC && kb <= kmaxC) {
+            const float cb_ = sah(kb);
+            if (cb_ < cost || (cb_ == cost && kb < k)) cost = cb_, k = kb;
+          }
+        }
+      }
+    }
+  }
+  // wave-min of (cost, position): lowest position among equal costs
+  unsigned long long key = ((unsigned long long)__float_as_uint(cost) << 32) | k;  // costs are >= 0: bit order == value order
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off, 64);
+    key = o < key ? o : key;
+  }
+  if (lane == 0) {
+    uint32_t kk = (uint32_t)key;
+    if ((uint32_t)(key >> 32) >= 0x7f800000u) kk = b + n / 2u;  // no finite candidate: the median always fits the budget
+    splitPos[w] = kk;
+    innerCnt[w] = (kk - b > leafMax ? 1u : 0u) + (e - kk > leafMax ? 1u : 0u);
+  }
+}
+
+// Write the node (packed + float form) and the next level's work items.
+__global__ void k_level_emit(const WorkItem* __restrict__ items, uint32_t count, uint32_t levelBase, uint32_t nextBase,
+                             const uint32_t* __restrict__ splitPos, const uint32_t* __restrict__ innerOff, uint32_t leafMax,
+                             const float4* __restrict__ segLo, const float4* __restrict__ segHi, uint32_t N2, float pad,
+                             float boxScale, uint4* __restrict__ nodes16, float4* __restrict__ nodesF, WorkItem* __restrict__ next) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= count) return;
+  const uint32_t b = items[w].b, e = items[w].e, k = splitPos[w];
+  uint32_t slot = innerOff[w];
+  int32_t child[2];
+  const uint32_t cb[2] = {b, k}, ce[2] = {k, e};
+  for (int c = 0; c < 2; ++c) {
+    if (ce[c] - cb[c] > leafMax) {
+      next[slot] = WorkItem{cb[c], ce[c]};
+      child[c] = (int32_t)(nextBase + slot);
+      ++slot;
+    } else {
+      child[c] = ~(int32_t)((cb[c] << 3) | (ce[c] - cb[c] - 1u));
+    }
+  }
+  Box3 B0 = range_box(segLo, segHi, N2, b, k), B1 = range_box(segLo, segHi, N2, k, e);
+  B0.lx -= pad, B0.ly -= pad, B0.lz -= pad, B0.hx += pad, B0.hy += pad, B0.hz += pad;
+  B1.lx -= pad, B1.ly -= pad, B1.lz -= pad, B1.hx += pad, B1.hy += pad, B1.hz += pad;
+  const uint32_t i = levelBase + w;
+  // float form (rtbvh::Node: lo0 hi0 lo1 hi1 child[2] pad[2])
+  nodesF[4 * (size_t)i + 0] = make_float4(B0.lx, B0.ly, B0.lz, B0.hx);
+  nodesF[4 * (size_t)i + 1] = make_float4(B0.hy, B0.hz, B1.lx, B1.ly);
+  nodesF[4 * (size_t)i + 2] = make_float4(B1.lz, B1.hx, B1.hy, B1.hz);
+  nodesF[4 * (size_t)i + 3] = make_float4(__int_as_float(child[0]), __int_as_float(child[1]), 0.f, 0.f);
+  // packed form (rtbvh::Node16: lo0[3] hi0[3] lo1[3] hi1[3] as binary16 of coordinate x boxScale, outward)
+  const float s = boxScale;
+  const uint32_t h[12] = {half_directed(B0.lx * s, false), half_directed(B0.ly * s, false), half_directed(B0.lz * s, false),
+                          half_directed(B0.hx * s, true),  half_directed(B0.hy * s, true),  half_directed(B0.hz * s, true),
+                          half_directed(B1.lx * s, false), half_directed(B1.ly * s, false), half_directed(B1.lz * s, false),
+                          half_directed(B1.hx * s, true),  half_directed(B1.hy * s, true),  half_directed(B1.hz * s, true)};
+  nodes16[2 * (size_t)i + 0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+  nodes16[2 * (size_t)i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, (uint32_t)child[0], (uint32_t)child[1]);
+}
+
+// 48-B triangle records (rtbvh::TriRec): p0, e1 = p1 - p0, e2 = p2 - p0 (the float subtraction
+// Ray.cpp:11 performs per test), global id, mesh; in `order` (leaf order) or reference order
+__global__ void k_tri_records(const float* __restrict__ vpos, const uint4* __restrict__ triShade, const uint32_t* __restrict__ order,
+                              uint32_t n, float4* __restrict__ recs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t t = order ? order[i] : i;
+  const uint4 tv = triShade[t];
+  const float* p0 = vpos + 3 * (size_t)tv.x;
+  const float* p1 = vpos + 3 * (size_t)tv.y;
+  const float* p2 = vpos + 3 * (size_t)tv.z;
+  const float e1x = p1[0] - p0[0], e1y = p1[1] - p0[1], e1z = p1[2] - p0[2];
+  const float e2x = p2[0] - p0[0], e2y = p2[1] - p0[1], e2z = p2[2] - p0[2];
+  recs[3 * (size_t)i + 0] = make_float4(p0[0], p0[1], p0[2], e1x);
+  recs[3 * (size_t)i + 1] = make_float4(e1y, e1z, e2x, e2y);
+  recs[3 * (size_t)i + 2] = make_float4(e2z, __uint_as_float(t), __uint_as_float(tv.w), 0.f);
+}
+
+#define GB_TRY(expr)            \
+  do {                          \
+    hipError_t e_ = (expr);     \
+    if (e_ != hipSuccess) {     \
+      cleanup();                \
+      return e_;                \
+    }                           \
+  } while (0)
+
+}  // namespace
+
+// Builds nodes16 / nodesF / tris / trisRef on the current device.  The output arrays are
+// hipMalloc'ed here and owned by the caller.  Returns hipSuccess and fills `out`.
+hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n, const rtbvh::ScenePlan& P, GpuBvh* out,
+                         hipStream_t stream) {
+  *out = GpuBvh{};
+  const uint32_t leafMax = P.leafMax;
+  uint32_t N2 = 1;
+  while (N2 < n) N2 <<= 1;
+  float4 *lo = nullptr, *hi = nullptr, *segLo = nullptr, *segHi = nullptr, *nodesF = nullptr, *tris = nullptr, *trisRef = nullptr;
+  uint4* nodes16 = nullptr;
+  int* cb = nullptr;
+  uint64_t *keys = nullptr, *keys2 = nullptr;
+  uint32_t *vals = nullptr, *order = nullptr, *splitPos = nullptr, *innerCnt = nullptr, *innerOff = nullptr;
+  WorkItem *itemsA = nullptr, *itemsB = nullptr;
+  void* tmp = nullptr;
+  bool keepOutputs = false;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)lo, (void*)hi, (void*)segLo, (void*)segHi, (void*)cb, (void*)keys, (void*)keys2, (void*)vals, (void*)order,
+                    (void*)splitPos, (void*)innerCnt, (void*)innerOff, (void*)itemsA, (void*)itemsB, tmp})
+      if (p) (void)hipFree(p);
+    if (!keepOutputs)
+      for (void* p : {(void*)nodes16, (void*)nodesF, (void*)tris, (void*)trisRef})
+        if (p) (void)hipFree(p);
+  };
+  const uint32_t maxNodes = n;  // a binary tree over n > leafMax triangles with >= 1 per leaf has < n inner nodes
+  GB_TRY(hipMalloc((void**)&lo, (size_t)n * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&hi, (size_t)n * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&segLo, 2 * (size_t)N2 * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&segHi, 2 * (size_t)N2 * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&cb, 6 * sizeof(int)));
+  GB_TRY(hipMalloc((void**)&keys, (size_t)n * sizeof(uint64_t)));
+  GB_TRY(hipMalloc((void**)&keys2, (size_t)n * sizeof(uint64_t)));
+  GB_TRY(hipMalloc((void**)&vals, (size_t)n * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&order, (size_t)n * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&splitPos, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&innerCnt, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&innerOff, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&itemsA, (size_t)maxNodes * sizeof(WorkItem)));
+  GB_TRY(hipMalloc((void**)&itemsB, (size_t)maxNodes * sizeof(WorkItem)));
+  GB_TRY(hipMalloc((void**)&nodes16, 2 * (size_t)maxNodes * sizeof(uint4)));
+  GB_TRY(hipMalloc((void**)&nodesF, 4 * (size_t)maxNodes * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&tris, 3 * (size_t)n * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&trisRef, 3 * (size_t)n * sizeof(float4)));
+  size_t sortBytes = 0, scanBytes = 0;
+  GB_TRY(rocprim::radix_sort_pairs(nullptr, sortBytes, keys, keys2, vals, order, n, 0, 63, stream));
+  GB_TRY(rocprim::exclusive_scan(nullptr, scanBytes, innerCnt, innerOff, 0u, (size_t)maxNodes, rocprim::plus<uint32_t>(), stream));
+  const size_t tmpBytes = sortBytes > scanBytes ? sortBytes : scanBytes;
+  GB_TRY(hipMalloc(&tmp, tmpBytes ? tmpBytes : 16));
+
+  const dim3 blk(256), grdN((n + 255) / 256);
+  hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, cb);
+  hipLaunchKernelGGL(k_tri_boxes, grdN, blk, 0, stream, dVpos, dTriShade, n, lo, hi, cb);
+  hipLaunchKernelGGL(k_morton, grdN, blk, 0, stream, lo, hi, n, cb, keys, vals);
+  GB_TRY(rocprim::radix_sort_pairs(tmp, sortBytes, keys, keys2, vals, order, n, 0, 63, stream));
+  hipLaunchKernelGGL(k_seg_leaves, dim3((N2 + 255) / 256), blk, 0, stream, lo, hi, order, n, N2, segLo, segHi);
+  for (uint32_t cnt = N2 / 2; cnt >= 1; cnt >>= 1)  // level with `cnt` nodes starts at index cnt
+    hipLaunchKernelGGL(k_seg_level, dim3((cnt + 255) / 256), blk, 0, stream, cnt, cnt, segLo, segHi);
+  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
+  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
+
+  // top-down, one level at a time
+  const WorkItem root{0u, n};
+  GB_TRY(hipMemcpyAsync(itemsA, &root, sizeof root, hipMemcpyHostToDevice, stream));
+  uint32_t count = 1, levelBase = 0, depth = 0, maxDepth = 0;
+  WorkItem *cur = itemsA, *nxt = itemsB;
+  while (count) {
+    if ((int)depth >= rtbvh::kMaxDepth - 1 || levelBase + count > maxNodes) {
+      cleanup();
+      return hipErrorInvalidValue;  // (cannot happen: the depth budget is enforced by the split choice)
+    }
+    hipLaunchKernelGGL(k_level_split, dim3((count + 3) / 4), dim3(256), 0, stream, cur, count, depth, P.depthCap, leafMax, segLo,
+                       segHi, N2, keys2, splitPos, innerCnt);
+    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, innerCnt, innerOff, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream));
+    const uint32_t nextBase = levelBase + count;
+    hipLaunchKernelGGL(k_level_emit, dim3((count + 255) / 256), blk, 0, stream, cur, count, levelBase, nextBase, splitPos, innerOff,
+                       leafMax, segLo, segHi, N2, P.pad, P.boxScale, nodes16, nodesF, nxt);
+    uint32_t lastOff = 0, lastCnt = 0;
+    GB_TRY(hipMemcpyAsync(&lastOff, innerOff + (count - 1), 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipMemcpyAsync(&lastCnt, innerCnt + (count - 1), 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipStreamSynchronize(stream));
+    maxDepth = depth + 1;  // leaves hang one level below the deepest inner level
+    levelBase = nextBase;
+    count = lastOff + lastCnt;
+    ++depth;
+    WorkItem* t = cur;
+    cur = nxt, nxt = t;
+  }
+  GB_TRY(hipGetLastError());
+  keepOutputs = true;
+  out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;
+  out->n_nodes = levelBase, out->maxDepth = maxDepth;
+  cleanup();
+  return hipSuccess;
+}
+
+}  // namespace rtk

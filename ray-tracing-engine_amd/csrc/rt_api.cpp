@@ -102,6 +102,11 @@ struct rt_ctx {
     uint32_t n = 0;
   };
   std::map<std::string, GranList> granules;
+  // device-built BVH (rt_options.bvh_builder / RT_BVH_GPU): the float form of the nodes stays
+  // on the device for rt_bvh_export
+  float4* dNodesF = nullptr;
+  uint32_t builder = RT_BVH_HOST;
+  float buildMs = 0.f;
   uint32_t numCUs = 0;
   hipEvent_t ev[kEventPairs][2];
   int evUsed = 0;
@@ -316,8 +321,18 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
 
   rt_ctx* c = new rt_ctx();
   c->device = opt ? opt->device : 0;
+  // the tree: host SAH builder, or the device builder (tiny scenes always take the host's
+  // special cases)
+  const bool gpuBuild = ((opt && opt->bvh_builder == RT_BVH_DEVICE) || getenv("RT_BVH_GPU")) && sc->n_triangles >= 16;
+  rtbvh::ScenePlan plan;
+  const auto tBuild0 = std::chrono::steady_clock::now();
   try {
-    rtbvh::build(*sc, opt ? opt->bvh_leaf_max : 0, c->bvh);
+    if (gpuBuild) {
+      plan = rtbvh::planScene(*sc, opt ? opt->bvh_leaf_max : 0);
+      c->bvh.leafMax = plan.leafMax, c->bvh.pad = plan.pad, c->bvh.originBound = plan.originBound, c->bvh.boxScale = plan.boxScale;
+    } else {
+      rtbvh::build(*sc, opt ? opt->bvh_leaf_max : 0, c->bvh);
+    }
   } catch (const std::exception& e) {
     delete c;
     return fail(RT_ERR_INVALID, "scene rejected: %s", e.what());
@@ -335,19 +350,35 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
     rt_destroy(c);                                         \
     return rc;                                             \
   }
-  UP(nodes, c->bvh.nodes16.data(), c->bvh.nodes16.size() * 2);
-  UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);
-  UP(trisRef, c->bvh.trisRef.data(), c->bvh.trisRef.size() * 3);
   UP(triShade, shade.data(), shade.size());
   UP(vpos, sc->vertex_pos, (size_t)sc->n_vertices * 3);
   UP(vnrm, sc->vertex_nrm, (size_t)sc->n_vertices * 3);
+  if (gpuBuild) {
+    rtk::GpuBvh G;
+    hipError_t he = rtk::gpu_bvh_build(S.vpos, S.triShade, sc->n_triangles, plan, &G, nullptr);
+    if (he != hipSuccess) {
+      rt_destroy(c);
+      return fail(RT_ERR_HIP, "device BVH build failed: %s", hipGetErrorString(he));
+    }
+    S.nodes = G.nodes16, S.tris = G.tris, S.trisRef = G.trisRef;
+    c->allocs.push_back(G.nodes16), c->allocs.push_back(G.tris), c->allocs.push_back(G.trisRef);
+    c->dNodesF = G.nodesF;
+    c->bvh.maxDepth = G.maxDepth;
+    S.n_nodes = G.n_nodes;
+    c->builder = RT_BVH_DEVICE;
+  } else {
+    UP(nodes, c->bvh.nodes16.data(), c->bvh.nodes16.size() * 2);
+    UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);
+    UP(trisRef, c->bvh.trisRef.data(), c->bvh.trisRef.size() * 3);
+    S.n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
+  }
+  c->buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count();
   UP(mats, sc->materials, sc->n_meshes);
   UP(lights, sc->lights, sc->n_lights);
   UP(meshTriBegin, sc->mesh_tri_begin, sc->n_meshes + 1);
   UP(meshVtxBegin, sc->mesh_vtx_begin, sc->n_meshes + 1);
 #undef UP
   S.n_tris = sc->n_triangles;
-  S.n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
   S.n_lights = sc->n_lights;
   S.n_photons = 0;
   S.invBoxScale = 1.f / c->bvh.boxScale;
@@ -392,6 +423,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->dTiles) (void)hipFree(c->dTiles);
   if (c->dCounters) (void)hipFree(c->dCounters);
   if (c->dTileCounter) (void)hipFree(c->dTileCounter);
+  if (c->dNodesF) (void)hipFree(c->dNodesF);
   for (auto& kv : c->granules)
     if (kv.second.d) (void)hipFree(kv.second.d);
   if (c->evReady)
@@ -627,16 +659,24 @@ int rt_knn(rt_ctx* c, const float* q3, uint32_t n, uint32_t k, uint32_t* idx, fl
 int rt_bvh_info_get(rt_ctx* c, rt_bvh_info* out) {
   if (!c || !out) return fail(RT_ERR_INVALID, "null argument");
   memset(out, 0, sizeof *out);
-  out->n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
-  out->n_tri_records = static_cast<uint32_t>(c->bvh.tris.size());
+  out->n_nodes = c->S.n_nodes;
+  out->n_tri_records = c->S.n_tris;
   out->max_depth = c->bvh.maxDepth;
   out->leaf_max = c->bvh.leafMax;
   out->pad = c->bvh.pad;
+  out->build_ms = c->buildMs;
+  out->builder = c->builder;
   return RT_OK;
 }
 
 int rt_bvh_export(rt_ctx* c, void* nodes64, void* tris48) {
   if (!c) return fail(RT_ERR_INVALID, "ctx is null");
+  if (c->builder == RT_BVH_DEVICE) {  // the arrays only exist on the device
+    HIP_TRY(hipSetDevice(c->device));
+    if (nodes64) HIP_TRY(hipMemcpy(nodes64, c->dNodesF, (size_t)c->S.n_nodes * sizeof(rtbvh::Node), hipMemcpyDeviceToHost));
+    if (tris48) HIP_TRY(hipMemcpy(tris48, c->S.tris, (size_t)c->S.n_tris * sizeof(rtbvh::TriRec), hipMemcpyDeviceToHost));
+    return RT_OK;
+  }
   if (nodes64) memcpy(nodes64, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node));
   if (tris48) memcpy(tris48, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(rtbvh::TriRec));
   return RT_OK;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bvh_build.h"
 #include "rt_amd.h"
 
 #define RTK_KMAX 16  // photon k-heap slots per lane (LDS budget, rt_kernels.hip)
@@ -77,6 +78,16 @@ hipError_t launch_knn(const DevScene& S, const float* q, uint32_t n, uint32_t k,
                       uint32_t* visited, hipStream_t stream);
 hipError_t launch_emit(const DevScene& S, uint32_t perLight, uint32_t seed, float4* outPos, float4* outDir,
                        unsigned long long* counters, hipStream_t stream);
+// scene BVH on the device (bvh_gpu.hip): arrays are hipMalloc'ed by the builder, owned by the caller
+struct GpuBvh {
+  uint4* nodes16 = nullptr;   // n_nodes x 32 B (what the kernels traverse)
+  float4* nodesF = nullptr;   // n_nodes x 64 B (rtbvh::Node: inspection / export)
+  float4* tris = nullptr;     // leaf (Morton) order
+  float4* trisRef = nullptr;  // reference order
+  uint32_t n_nodes = 0, maxDepth = 0;
+};
+hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n_tris, const rtbvh::ScenePlan& plan, GpuBvh* out,
+                         hipStream_t stream);
 // photon map on the device (kd_build.hip)
 hipError_t launch_photon_compact(const float4* slots, uint32_t n, float4* items, uint32_t* count, hipStream_t stream);
 hipError_t launch_kd_build(float4* items, uint32_t n, int depthOverride, hipStream_t stream);

@@ -19,6 +19,7 @@ RT_OK = 0
 MODE_RAY, MODE_PATH = 0, 1
 RNG_LEGACY, RNG_PIXEL = 0, 1
 ACCEL_BVH, ACCEL_BRUTE = 0, 1
+BVH_HOST, BVH_DEVICE = 0, 1
 TRACE_CLOSEST, TRACE_ANY = 0, 1
 (UNIT_ASIN, UNIT_SINF, UNIT_COSF, UNIT_STREAM_SEED, UNIT_TRIANGLE, UNIT_BSDF, UNIT_RAY_AT, UNIT_LIGHT_EVAL,
  UNIT_SAMPLERS, UNIT_LIGHT_SAMPLE, UNIT_POW) = range(11)
@@ -55,7 +56,7 @@ class SceneDesc(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("device", C.c_int32), ("bvh_leaf_max", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+    _fields_ = [("device", C.c_int32), ("bvh_leaf_max", C.c_uint32), ("bvh_builder", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class Params(C.Structure):
@@ -76,7 +77,8 @@ class Stats(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_tri_records", C.c_uint32), ("max_depth", C.c_uint32),
-                ("leaf_max", C.c_uint32), ("pad", C.c_float), ("reserved", C.c_uint32 * 3)]
+                ("leaf_max", C.c_uint32), ("pad", C.c_float), ("build_ms", C.c_float), ("builder", C.c_uint32),
+                ("reserved", C.c_uint32 * 1)]
 
 
 RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3)])
@@ -256,10 +258,10 @@ def kd_order(pos, dir_, weight=None):
 class Context:
     """rt_ctx: the scene resident in HBM on one gfx950 device."""
 
-    def __init__(self, scene, device=0, bvh_leaf_max=0):
+    def __init__(self, scene, device=0, bvh_leaf_max=0, bvh_builder=0):
         self.scene = scene
         opt = Options()
-        opt.device, opt.bvh_leaf_max = device, bvh_leaf_max
+        opt.device, opt.bvh_leaf_max, opt.bvh_builder = device, bvh_leaf_max, bvh_builder
         h = C.c_void_p()
         _check(amd().rt_create(scene.desc_ptr, C.byref(opt), C.byref(h)))
         self._h = h

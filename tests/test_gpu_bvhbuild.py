@@ -1,0 +1,123 @@
+"""The BVH built on the device (csrc/bvh_gpu.hip, rt_options.bvh_builder = RT_BVH_DEVICE):
+same arrays, same exactness bar as the host SAH builder — BVH == exhaustive loop ==
+oracle on all four scenes — plus the structural invariants, the depth cap, determinism,
+build time and traversal cost next to the host tree.  (The whole GPU suite also runs on
+device-built trees with RT_BVH_GPU=1.)"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import pyrt
+from raybatch import ray_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("kind,n_loop,n_bvh", [("cubes", 60000, 0), ("lowres", 40000, 300000), ("hires", 30000, 300000),
+                                               ("stress", 1500, 150000)])
+def test_device_built_tree_is_exact(kind, n_loop, n_bvh):
+    s = pyrt.Scene(kind, 256, 256)
+    ctx = pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE)
+    bi = ctx.bvh_info()
+    if kind == "cubes":
+        assert bi.builder == pyrt.BVH_DEVICE or s.desc.n_triangles < 16
+    else:
+        assert bi.builder == pyrt.BVH_DEVICE
+    rays = ray_batch(s, n_loop, 4321)
+    ref = orc.trace(s, rays)
+    h = ctx.trace(rays, pyrt.ACCEL_BVH)
+    assert np.array_equal(h.view(np.uint8), ref.view(np.uint8))
+    assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BVH, pyrt.TRACE_ANY)["hit"], ref["hit"])
+    assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BRUTE).view(np.uint8), ref.view(np.uint8))  # (its trisRef too)
+    if n_bvh:
+        rays = ray_batch(s, n_bvh, 99)
+        assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BVH).view(np.uint8), orc.trace(s, rays, orc.ACCEL_OBVH).view(np.uint8))
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["lowres", "hires"])
+def test_device_tree_structure_and_determinism(kind):
+    s = pyrt.Scene(kind, 64, 64)
+    ctx = pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE)
+    bi = ctx.bvh_info()
+    nodes, tris = ctx.bvh_export()
+    host = pyrt.Context(s)
+    hb = host.bvh_info()
+    assert bi.n_tri_records == s.desc.n_triangles and bi.leaf_max == 2 and bi.pad == hb.pad
+    assert bi.max_depth <= hb.max_depth + 1 and bi.max_depth < 32  # the same depth cap binds both builders
+    ids = tris[:, 9]
+    assert sorted(ids.tolist()) == list(range(s.desc.n_triangles))
+    seen = np.zeros(bi.n_tri_records, bool)
+    lo = nodes[:, [0, 1, 2, 6, 7, 8]].view(np.float32).reshape(-1, 2, 3)
+    hi = nodes[:, [3, 4, 5, 9, 10, 11]].view(np.float32).reshape(-1, 2, 3)
+    tf = tris.view(np.float32)
+    reached = np.zeros(bi.n_nodes, bool)
+    reached[0] = True
+    for ni in range(bi.n_nodes):
+        for c in range(2):
+            ch = int(np.int32(nodes[ni, 12 + c]))
+            if ch < 0:
+                code = (~ch) & 0xFFFFFFFF
+                first, cnt = code >> 3, (code & 7) + 1
+                assert cnt <= bi.leaf_max and not seen[first:first + cnt].any()
+                seen[first:first + cnt] = True
+                p0 = tf[first:first + cnt, 0:3]
+                verts = np.stack([p0, p0 + tf[first:first + cnt, 3:6], p0 + tf[first:first + cnt, 6:9]], 1)
+                assert (verts >= lo[ni, c] - 1e-6).all() and (verts <= hi[ni, c] + 1e-6).all()
+            else:
+                assert ni < ch < bi.n_nodes and not reached[ch]  # breadth-first numbering: children after parents
+                reached[ch] = True
+                assert (lo[ch] >= lo[ni, c] - 1e-6).all() and (hi[ch] <= hi[ni, c] + 1e-6).all()
+    assert seen.all() and reached.all()
+    again = pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE)
+    n2, t2 = again.bvh_export()
+    assert np.array_equal(n2, nodes) and np.array_equal(t2, tris)  # same arrays on every build
+    for c in (ctx, host, again):
+        c.close()
+
+
+@pytest.mark.parametrize("kind,w,h,spp", [("lowres", 64, 48, 6), ("hires", 48, 48, 4), ("stress", 32, 32, 2)])
+def test_frames_on_device_built_tree_vs_oracle(kind, w, h, spp):
+    s = pyrt.Scene(kind, w, h)
+    ctx = pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE)
+    p = pyrt.make_params(w, h, spp, seed=31)
+    _, acc, st = ctx.render(p)
+    _, ref, rst = orc.render(s, p, math_mode=orc.MATH_DET, accel=orc.ACCEL_OBVH)
+    assert np.array_equal(bits(acc), bits(ref)) and (st.rays_closest, st.rays_shadow) == (rst.rays_closest, rst.rays_shadow)
+    ctx.close()
+
+
+def test_build_time_and_tree_quality_report(capsys):
+    """Reported, with loose guards: the device build of the 1M-triangle scene must beat the
+    host build's time, and its traversal cost (nodes per ray on a fixed ray batch) must
+    stay within 1.35x of the host SAH tree's (measured values go to DESIGN.md)."""
+    rows = []
+    for kind, n in (("lowres", 200000), ("hires", 200000), ("stress", 200000)):
+        s = pyrt.Scene(kind, 256, 256)
+        out = {}
+        for name, b in (("host", pyrt.BVH_HOST), ("device", pyrt.BVH_DEVICE)):
+            ctx = pyrt.Context(s, bvh_builder=b)
+            bi = ctx.bvh_info()
+            p = pyrt.make_params(256, 256, 4, seed=2, collect_stats=1)
+            _, _, st = ctx.render(p, want_accum=False)
+            rays = st.rays_closest + st.rays_shadow
+            out[name] = (bi.build_ms, bi.n_nodes, bi.max_depth, st.nodes_visited / rays, st.tris_tested / rays, st.kernel_ms)
+            ctx.close()
+        rows.append((kind, out))
+    with capsys.disabled():
+        for kind, out in rows:
+            print("\n%-7s host: build %8.1f ms nodes %7d depth %2d  %.2f nodes/ray %.2f tris/ray kernel %.2f ms | "
+                  "device: build %7.1f ms nodes %7d depth %2d  %.2f nodes/ray %.2f tris/ray kernel %.2f ms"
+                  % ((kind,) + out["host"] + out["device"]), end="")
+        print()
+    for kind, out in rows:
+        assert out["device"][3] < 1.35 * out["host"][3], (kind, out)
+    stress = dict(rows)["stress"]
+    if not os.environ.get("RT_BVH_GPU"):  # (the variable forces the device builder for "host" too)
+        assert stress["device"][0] < stress["host"][0]
