@@ -236,6 +236,12 @@ int rt_group_render(rt_group* g, const rt_params* p, const float* background_rgb
  * rays that start farther out are answered by the exhaustive loop, transparently. */
 int rt_trace(rt_ctx* ctx, const rt_ray* rays, uint32_t n, uint32_t accel,
              uint32_t kind, rt_hit* hits);
+/* RayTracer::rayTrace over a ray QUEUE resident in HBM (the trace stage of the wavefront
+ * integrator; also a device-to-device form of rt_trace): ray_o[i] = origin xyz + kind bits
+ * in w (bit 0: any-hit), ray_d[i] = direction xyz (float4 each); res[i] (uint2) = closest
+ * hit {t bits, global triangle id} or {~0, ~0}, any-hit {0 / 1, 0}. */
+int rt_trace_stream_device(rt_ctx* ctx, const void* d_ray_o, const void* d_ray_d, uint32_t n,
+                           void* d_res, void* stream);
 int rt_knn(rt_ctx* ctx, const float* query3, uint32_t n, uint32_t k,
            uint32_t* idx_out /*[n][k]*/, float* dist_out /*[n][k]*/,
            uint32_t* visited_out /*[n] or NULL*/);

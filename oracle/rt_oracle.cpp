@@ -463,6 +463,17 @@ struct Ctx {
   Counters cnt;
   const OBvh* bvh = nullptr;  // optional CPU acceleration (same results, see OBvh)
   uint64_t nodes = 0;
+  // diagnostics (tools/stream_bench.py): every ray cast, as {o.xyz, kind | depth << 8, d.xyz, 0}
+  std::vector<float>* dump = nullptr;
+  int depthNow = 0;
+  void record(const Ray& r, uint32_t kind) {
+    if (!dump) return;
+    const uint32_t tag = kind | ((uint32_t)depthNow << 8);
+    float t;
+    memcpy(&t, &tag, 4);
+    const float v[8] = {r.o.x, r.o.y, r.o.z, t, r.d.x, r.d.y, r.d.z, 0.f};
+    dump->insert(dump->end(), v, v + 8);
+  }
 };
 
 inline V3 interp(const float* arr, const uint32_t* iv, float w, float u, float v) {
@@ -508,6 +519,7 @@ inline V3 shade(Ctx& c, Engine& e, const Ray& ray, const Hit& h, V3& hitNormal,
     const rt_light& L = sc.lights[li];
     V3 toLight = randAreaPosition(e, L) - trianglePoint;
     c.cnt.shadow++;
+    c.record(Ray{trianglePoint, toLight}, 1u);
     if (rayTrace(sc, Ray{trianglePoint, toLight}, &c.cnt, c.bvh, true, &c.nodes).found) continue;
     V3 bsdf = evaluateColorResponse(mat, c.M, hitNormal, toLight, -ray.d);
     V3 radiance = evaluateLight(L, trianglePoint);
@@ -526,6 +538,8 @@ inline V3 integrate(Ctx& c, Engine& e, Ray ray, int mode, int finalDepth, bool& 
   if (maxv > 8) maxv = 8;
   for (int depth = 0; depth < maxv; depth++) {
     c.cnt.closest++;
+    c.depthNow = depth;
+    c.record(ray, 0u);
     Hit h = rayTrace(c.sc, ray, &c.cnt, c.bvh, false, &c.nodes);
     if (!(h.found && h.d > 0.f)) {
       if (depth == 0) found = false;
@@ -631,11 +645,14 @@ typedef struct orc_opts {
   uint32_t n_ext_photons;
   uint32_t engine_state;    // legacy: initial engine state (1 = default seed)
   uint32_t accel;           // 0 = the reference's exhaustive loop, 1 = OBvh (same results)
+  float* ray_dump;          // diagnostics: every ray cast (8 floats each), single-threaded runs only
+  uint64_t ray_dump_cap;    // capacity in rays
+  uint64_t ray_dump_count;  // out
 } orc_opts;
 
 // Whole Renderer::render (Renderer.cpp:203-272) on the flat scene.  accum_out
 // (optional) = [h][w][4] {sum rgb, primary-hit count}.
-int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
+int orc_render(const rt_scene_desc* sc, const rt_params* p, orc_opts* o,
                const float* background_rgb, float* out_rgb, float* accum_out,
                rt_stats* stats) {
   const uint32_t w = p->width, h = p->height, N = p->spp;
@@ -692,6 +709,8 @@ int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
 #pragma omp parallel num_threads(nth)
     {
       Ctx c{*sc, M, &tree, (int)p->k, (int)p->photons_requested, Counters(), bvh};
+      std::vector<float> dumpBuf;
+      if (o && o->ray_dump && nth == 1) c.dump = &dumpBuf;
 #pragma omp for schedule(dynamic, 4)
       for (int64_t y = 0; y < (int64_t)h; y++)
         for (uint32_t x = 0; x < w; x++) {
@@ -706,6 +725,11 @@ int orc_render(const rt_scene_desc* sc, const rt_params* p, const orc_opts* o,
         total.closest += c.cnt.closest, total.shadow += c.cnt.shadow, total.knn += c.cnt.knn;
         total.tri_tests += c.cnt.tri_tests, total.kd_visited += c.cnt.kd_visited;
         nodesTotal += c.nodes;
+        if (c.dump) {
+          const uint64_t nr = std::min<uint64_t>(dumpBuf.size() / 8, o->ray_dump_cap);
+          memcpy(o->ray_dump, dumpBuf.data(), nr * 32);
+          o->ray_dump_count = nr;
+        }
       }
     }
   }

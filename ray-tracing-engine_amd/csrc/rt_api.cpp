@@ -749,6 +749,18 @@ int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint
   return RT_OK;
 }
 
+// ------------------------------------------------------------------ ray streams
+int rt_trace_stream_device(rt_ctx* c, const void* d_ray_o, const void* d_ray_d, uint32_t n, void* d_res, void* stream) {
+  if (!c || (n && (!d_ray_o || !d_ray_d || !d_res))) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  const uint32_t levels = (c->bvh.maxDepth > 1 ? c->bvh.maxDepth : 1) + 1u;
+  hipError_t he = rtk::launch_trace_stream(c->S, static_cast<const float4*>(d_ray_o), static_cast<const float4*>(d_ray_d), n,
+                                           static_cast<uint2*>(d_res), c->dTileCounter, levels, c->numCUs,
+                                           static_cast<hipStream_t>(stream));
+  if (he != hipSuccess) return fail(RT_ERR_HIP, "stream trace launch failed: %s", hipGetErrorString(he));
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------ photon map on the device
 int rt_build_photon_map(rt_ctx* c, uint32_t n_requested, uint32_t seed, uint32_t* n_stored, double* ms_out) {
   if (!c || !n_stored) return fail(RT_ERR_INVALID, "ctx/n_stored is null");

@@ -68,6 +68,9 @@ hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevSce
                          float4* accum, unsigned long long* counters, hipStream_t stream);
 hipError_t launch_resolve(uint32_t n_pixels, uint32_t spp, const float4* accum, const float* bg, float* out,
                           hipStream_t stream);
+// ray queue in HBM -> results (wavefront stage T)
+hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const float4* rayD, uint32_t n, uint2* res,
+                               uint32_t* counter, uint32_t stackLevels, uint32_t numCUs, hipStream_t stream);
 // multi-GPU frame assembly: pack (unpack = false) a rank's owned granules out of a full-frame
 // accumulator, or scatter a packed buffer back into one
 hipError_t launch_pack(bool unpack, const float4* src, float4* dst, const uint32_t* gran, uint32_t n, uint32_t width,

@@ -678,22 +678,21 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   for (;;) {
     const uint64_t idle = __ballot(!T.live());
     const int nIdle = __popcll(idle);
+    // a lane may be given a ray (hand-out) or a subtree of one (stealing); the ray is
+    // started in ONE place below, so that the traversal state has a single definition
+    // point per iteration (two start sites cost ~25 register copies per round)
+    bool newRay = false, newShared = false;
+    uint32_t newK = 0, newJ = 0;
+    int32_t newNode = 0;
     if (head < R) {
       if (nIdle >= (int)S.refillT || nIdle == 64) {
-        if (!T.live()) {
-          const uint32_t r = head + lanes_below(idle);
-          if (r < R) {
-            // the bounce rays (closest hit: the longest walks) are handed out first
-            uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);  // r / n for kinds <= POOL_L + 1
-            const uint32_t j = listB[r - k * n];
-            k = bounce ? (k == 0 ? nl : k - 1) : k;
-            const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
-            const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BDIR;
-            const f3 dj = mk(fp[src + j], fp[src + 64 + j], fp[src + 128 + j]);
-            T.start(pj, dj, S.invBoxScale);
-            T.anyHit = k < nl, T.pj = j;
-            myK = k, myJ = j;
-          }
+        const uint32_t r = head + lanes_below(idle);
+        if (!T.live() && r < R) {
+          // the bounce rays (closest hit: the longest walks) are handed out first
+          uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);  // r / n for kinds <= POOL_L + 1
+          const uint32_t j = listB[r - k * n];
+          k = bounce ? (k == 0 ? nl : k - 1) : k;
+          newRay = true, newK = k, newJ = j;
         }
         head += (uint32_t)nIdle;
       }
@@ -737,21 +736,23 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
         const uint32_t v = w & 63u, e = w >> 6;
         const uint32_t kj = (uint32_t)__shfl((int)(myK | (myJ << 8)), (int)v, 64);  // (all lanes take part)
         if (thief) {
-          const uint32_t k = kj & 255u, j = kj >> 8;
           uint32_t* slot = stackBase + (e + 1u) * BLOCK + v;  // (row 0 is the sentinel)
-          const int32_t node = (int32_t)*slot;
+          newNode = (int32_t)*slot;
           *slot = (uint32_t)TERM;
-          const f3 pj = mk(fp[VP_PT + j], fp[VP_PT + 64 + j], fp[VP_PT + 128 + j]);
-          const uint32_t src = k < nl ? VP_DIR + 192 * k : VP_BDIR;
-          const f3 dj = mk(fp[src + j], fp[src + 64 + j], fp[src + 128 + j]);
-          T.start(pj, dj, S.invBoxScale);
-          T.cur = node;
-          T.anyHit = k < nl, T.pj = j, T.shared = true;
-          myK = k, myJ = j;
+          newRay = true, newShared = true, newK = kj & 255u, newJ = kj >> 8;
         }
         wave_sync();
       }
       PH(PH_STEAL);
+    }
+    if (newRay) {
+      const f3 pj = mk(fp[VP_PT + newJ], fp[VP_PT + 64 + newJ], fp[VP_PT + 128 + newJ]);
+      const uint32_t src = newK < nl ? VP_DIR + 192 * newK : VP_BDIR;
+      const f3 dj = mk(fp[src + newJ], fp[src + 64 + newJ], fp[src + 128 + newJ]);
+      T.start(pj, dj, S.invBoxScale);
+      if (T.live()) T.cur = newNode;  // (a NaN ray stays dead)
+      T.anyHit = newK < nl, T.pj = newJ, T.shared = newShared;
+      myK = newK, myJ = newJ;
     }
     if (__ballot(T.live()) == 0) break;
     if (T.shared && T.live()) {
@@ -1017,6 +1018,90 @@ __global__ void k_resolve(uint32_t n_pixels, float spp, const float4* __restrict
   out[3 * i + 0] = a.x / spp + bg[3 * i + 0] * miss / spp;
   out[3 * i + 1] = a.y / spp + bg[3 * i + 1] * miss / spp;
   out[3 * i + 2] = a.z / spp + bg[3 * i + 2] * miss / spp;
+}
+
+// ---------------------------------------------------------------- ray streams (wavefront stage T)
+// RayTracer::rayTrace (RayTracer.h:27-53) over a QUEUE of rays in HBM instead of the rays of
+// one wave's pixels: persistent waves draw rays from a global counter — whenever enough
+// lanes have finished, they are refilled in one step (ballot + mbcnt compaction, one atomic
+// per refill) — so the 64 lanes of a wave stay busy however unequal the rays are, and the
+// kernel carries no shading state: 64 VGPRs, 8 waves per SIMD.
+//   rayO[i] = origin xyz, w = kind bits (bit 0: any-hit);  rayD[i] = direction xyz
+//   res[i]  = closest: {t bits, triangle id} or {~0, ~0};  any-hit: {hit ? 1 : 0, 0}
+constexpr int STREAM_CHUNK = 2048;
+template <int LT>
+__global__ __launch_bounds__(1024, 8) void k_trace_stream(DevScene S, const float4* __restrict__ rayO,
+                                                          const float4* __restrict__ rayD, uint32_t n,
+                                                          uint2* __restrict__ res, uint32_t* __restrict__ counter,
+                                                          uint32_t stackLevels) {
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  if (LT != LT_NONE) {
+    uint4* dst = reinterpret_cast<uint4*>(g_lds);
+    for (uint32_t i = threadIdx.x; i < 2u * S.topK; i += blockDim.x) dst[i] = S.nodes[i];
+    __syncthreads();
+  }
+  uint32_t* stack = g_lds + 8u * S.topK + wv * stackLevels * BLOCK + lane;
+  Trav<TRAV_MIXED, LT> T;
+  T.idle(stack);
+  T.sharedKey = nullptr, T.pj = 0;
+  LaneStats st;
+  uint32_t mine = ~0u;
+  // A wave reserves STREAM_CHUNK rays at a time (one atomic on the shared counter per chunk:
+  // every wave of the chip hitting ONE address per refill was the bottleneck, 3 Grays/s) and
+  // STAGES them 64 at a time in registers: lane L holds ray (block + L), loaded one refill
+  // before it is needed, so the HBM/L2 latency of a ray record hides behind a traversal
+  // round.  Lanes that finished take the staged rays in order, through a lane shuffle.
+  uint32_t cur = 0, end = 0;      // unstaged rest of the chunk
+  uint32_t sBase = 0, sHead = 64;  // staged block: ray index of entry 0, next entry to hand out
+  uint32_t sCount = 0;             // entries of the staged block that exist
+  float4 so = make_float4(0.f, 0.f, 0.f, 0.f), sd = so;
+  bool more = true;  // rays left to stage
+  for (;;) {
+    const uint64_t idle = __ballot(!T.live());
+    const int nIdle = __popcll(idle);
+    if ((nIdle >= (int)S.refillT || nIdle == 64) && (sHead < sCount || more)) {
+      if (sHead < sCount) {
+        const uint32_t r = sHead + lanes_below(idle);
+        const bool take = !T.live() && r < sCount;
+        const int src = take ? (int)r : (int)lane;
+        const float ox = __shfl(so.x, src, 64), oy = __shfl(so.y, src, 64), oz = __shfl(so.z, src, 64), ow = __shfl(so.w, src, 64);
+        const float dx = __shfl(sd.x, src, 64), dy = __shfl(sd.y, src, 64), dz = __shfl(sd.z, src, 64);
+        if (take) {
+          T.start(mk(ox, oy, oz), mk(dx, dy, dz), S.invBoxScale);
+          T.anyHit = (__float_as_uint(ow) & 1u) != 0u;
+          mine = sBase + r;
+          // (a ray with a NaN component is dead on arrival: Trav::start — it hits nothing)
+          if (!T.live()) res[mine] = T.anyHit ? make_uint2(0u, 0u) : make_uint2(~0u, ~0u), mine = ~0u;
+        }
+        sHead = sHead + (uint32_t)nIdle < sCount ? sHead + (uint32_t)nIdle : sCount;
+      }
+      if (sHead >= sCount && more) {  // stage the next 64 (consumed at a later refill)
+        if (cur == end) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(counter, (uint32_t)STREAM_CHUNK);
+          cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          end = cur + (uint32_t)STREAM_CHUNK < n ? cur + (uint32_t)STREAM_CHUNK : n;
+          if (cur >= n) cur = end = n, more = false;
+        }
+        if (more) {
+          sBase = cur, sHead = 0, sCount = end - cur < 64u ? end - cur : 64u;
+          if (lane < sCount) so = rayO[cur + lane], sd = rayD[cur + lane];
+          cur += sCount;
+        }
+      }
+    }
+    if (__ballot(T.live()) == 0) {
+      if (!more) break;
+      continue;
+    }
+    const bool was = T.live();
+    T.template round<false>(S, st);
+    if (was && !T.live()) {
+      res[mine] = T.anyHit ? make_uint2(T.found ? 1u : 0u, 0u)
+                           : (T.found ? make_uint2(__float_as_uint(T.hit.t), T.hit.id) : make_uint2(~0u, ~0u));
+      mine = ~0u;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- frame assembly (multi-GPU)
@@ -1335,6 +1420,38 @@ hipError_t launch_resolve(uint32_t n_pixels, uint32_t spp, const float4* accum, 
   if (n_pixels == 0) return hipSuccess;
   hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, n_pixels, (float)spp, accum,
                      bg, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const float4* rayD, uint32_t n, uint2* res,
+                               uint32_t* counter, uint32_t stackLevels, uint32_t numCUs, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  // LDS: [tree, if all of it fits beside the stacks][16 waves x stack]; two workgroups per CU
+  const uint32_t total = 160u * 1024u / 4u / 2u - 32u;  // words per workgroup
+  uint32_t wpw = 16u;                                   // waves per workgroup: as many as the stacks allow
+  while (wpw > 1u && wpw * stackLevels * BLOCK > total) --wpw;
+  const uint32_t stackWords = wpw * stackLevels * BLOCK;
+  static const int kEnv = getenv("RT_STREAM_TOPK") ? atoi(getenv("RT_STREAM_TOPK")) : -1;
+  DevScene S2 = S;
+  S2.topK = 0;
+  if (stackWords > total) return hipErrorInvalidValue;
+  if (stackWords + 8u * S.n_nodes <= total) S2.topK = S.n_nodes;
+  if (kEnv >= 0) S2.topK = (uint32_t)kEnv < S2.topK ? (uint32_t)kEnv : S2.topK;
+  const uint32_t ldsBytes = 4u * (8u * S2.topK + stackWords);
+  const uint32_t waves = (n + 63u) / 64u;
+  uint32_t wgs = (waves + wpw - 1u) / wpw;
+  wgs = wgs < 2u * numCUs ? wgs : 2u * numCUs;
+  if (S2.topK >= S.n_nodes && S2.topK) {
+    static bool once = false;
+    if (!once) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_stream<LT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), once = true;
+    hipLaunchKernelGGL((k_trace_stream<LT_ALL>), dim3(wgs), dim3(64u * wpw), ldsBytes, stream, S2, rayO, rayD, n, res, counter, stackLevels);
+  } else {
+    static bool once = false;
+    if (!once) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_stream<LT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), once = true;
+    hipLaunchKernelGGL((k_trace_stream<LT_NONE>), dim3(wgs), dim3(64u * wpw), ldsBytes, stream, S2, rayO, rayD, n, res, counter, stackLevels);
+  }
   return hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("mesh", "<u4"), ("tri", "<u4"), ("vtx", "
 AMD_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_photons", "rt_emit_photons",
                "rt_render", "rt_render_passes", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
                "rt_bvh_export", "rt_bvh_build_host", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
-               "rt_build_photon_map", "rt_get_photons", "rt_test_kd_order", "rt_owned_granules", "rt_pack_owned_device", "rt_unpack_owned_device", "rt_group_create", "rt_group_destroy",
+               "rt_trace_stream_device", "rt_build_photon_map", "rt_get_photons", "rt_test_kd_order", "rt_owned_granules", "rt_pack_owned_device", "rt_unpack_owned_device", "rt_group_create", "rt_group_destroy",
                "rt_group_size", "rt_group_uses_rccl", "rt_group_ctx", "rt_group_set_photons", "rt_group_render"]
 HOST_SYMBOLS = ["rt_host_scene_build", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error",
                 "rt_host_fill_background", "rt_host_save_ppm", "rt_host_kd_order"]
@@ -140,6 +140,7 @@ def amd():
         L.rt_profile_reset.argtypes = [C.c_void_p]
         L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.rt_test_unit.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.rt_trace_stream_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rt_build_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         L.rt_get_photons.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.rt_test_kd_order.argtypes = [C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
@@ -342,6 +343,10 @@ class Context:
     def resolve_device(self, width, height, spp, d_accum_ptr, d_bg_ptr, d_out_ptr, stream=0):
         _check(amd().rt_resolve_device(self._h, width, height, spp, C.c_void_p(d_accum_ptr), C.c_void_p(d_bg_ptr),
                                        C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def trace_stream_device(self, d_ray_o, d_ray_d, n, d_res, stream=0):
+        _check(amd().rt_trace_stream_device(self._h, C.c_void_p(d_ray_o), C.c_void_p(d_ray_d), n, C.c_void_p(d_res),
+                                            C.c_void_p(stream)))
 
     def pack_owned(self, params, d_accum_ptr, d_packed_ptr, stream=0):
         _check(amd().rt_pack_owned_device(self._h, C.byref(params), C.c_void_p(d_accum_ptr), C.c_void_p(d_packed_ptr),

@@ -16,7 +16,8 @@ MATH_LIBM, MATH_DET = 0, 1
 
 class Opts(C.Structure):
     _fields_ = [("math_mode", C.c_int32), ("threads", C.c_int32), ("ext_photons", C.c_void_p),
-                ("n_ext_photons", C.c_uint32), ("engine_state", C.c_uint32), ("accel", C.c_uint32)]
+                ("n_ext_photons", C.c_uint32), ("engine_state", C.c_uint32), ("accel", C.c_uint32),
+                ("ray_dump", C.c_void_p), ("ray_dump_cap", C.c_uint64), ("ray_dump_count", C.c_uint64)]
 
 
 _lib = None
@@ -99,6 +100,20 @@ def render(scene, params, math_mode=MATH_LIBM, threads=0, ext_photons=None, bg=N
     if rc != 0:
         raise RuntimeError("orc_render failed: %d" % rc)
     return out, acc, st
+
+
+def dump_rays(scene, params, cap=40_000_000):
+    """Every ray the pixel-mode frame casts, in casting order: array [n][8] = o.xyz, tag, d.xyz, 0
+    with tag (uint32 bits) = kind (0 closest, 1 shadow) | path depth << 8.  Single-threaded."""
+    o = Opts()
+    o.math_mode, o.threads, o.engine_state, o.accel = MATH_DET, 1, 1, ACCEL_OBVH
+    buf = np.zeros((cap, 8), np.float32)
+    o.ray_dump, o.ray_dump_cap = buf.ctypes.data, cap
+    acc = np.empty((params.height, params.width, 4), np.float32)
+    st = pyrt.Stats()
+    rc = lib().orc_render(scene.desc_ptr, C.byref(params), C.byref(o), None, None, _p(acc), C.byref(st))
+    assert rc == 0
+    return buf[:o.ray_dump_count].copy()
 
 
 def trace(scene, rays, accel=ACCEL_LOOP, kind=pyrt.TRACE_CLOSEST):
