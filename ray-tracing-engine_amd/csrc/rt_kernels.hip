@@ -1442,7 +1442,8 @@ hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const floa
   const uint32_t ldsBytes = 4u * (8u * S2.topK + stackWords);
   const uint32_t waves = (n + 63u) / 64u;
   uint32_t wgs = (waves + wpw - 1u) / wpw;
-  wgs = wgs < 2u * numCUs ? wgs : 2u * numCUs;
+  static const uint32_t perCU = getenv("RT_STREAM_WGS") ? (uint32_t)atoi(getenv("RT_STREAM_WGS")) : 2u;
+  wgs = wgs < perCU * numCUs ? wgs : perCU * numCUs;
   if (S2.topK >= S.n_nodes && S2.topK) {
     static bool once = false;
     if (!once) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_stream<LT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), once = true;

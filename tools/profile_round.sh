@@ -1,18 +1,28 @@
 #!/bin/bash
-# Round measurements on the GPU box: bench lines for C1-C5, rocprofv3 kernel stats of the
-# default bench command, HBM traffic (PMC) of C2 and C5.  Output: gpurun_out/round/.
+# Round-2 measurements on the GPU box (one gpurun call): bench lines of every workload (each
+# with its own in-run rocprofv3 PMC passes), rocprofv3 kernel stats of the default bench
+# command, the wide PMC sets of C2 and C5, section clocks of the pooled kernel, the builders'
+# report, the stream-vs-megakernel comparison.  Output: gpurun_out/round2/ (copy the
+# summaries to profiles/ with tools/collect_profiles.py).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/round; mkdir -p $out
-python3 bench.py > $out/bench_C2.log 2>&1; grep '^{' $out/bench_C2.log > $out/bench_C2.json
-for w in C1 C3 C4 C5; do
-  python3 bench.py --workload $w --no-cpu-baseline > $out/bench_$w.log 2>&1; grep '^{' $out/bench_$w.log > $out/bench_$w.json
+out=gpurun_out/round2; mkdir -p $out
+python3 bench.py --steps 20 --warmup 5 > $out/bench_C2.log 2>&1; grep '^{' $out/bench_C2.log > $out/bench_C2.json
+echo "C2 done"
+for w in C1 C3 C4 C5 C5x8; do
+  python3 bench.py --workload $w --no-cpu-baseline --steps 5 --warmup 2 > $out/bench_$w.log 2>&1; grep '^{' $out/bench_$w.log > $out/bench_$w.json
+  echo "$w done"
 done
-echo bench done
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline > $out/prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline --no-pmc --steps 20 --warmup 5 > $out/prof.log 2>&1
 find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/c2_kernel_stats.csv \;
-echo prof done
-tools/traffic.sh C2 > $out/traffic_C2.log 2>&1
-tools/traffic.sh C5 > $out/traffic_C5.log 2>&1
-cp gpurun_out/traffic_C2.json gpurun_out/traffic_C5.json $out/ 2>/dev/null
-echo traffic done
+grep '^{' $out/prof.log > $out/bench_C2_under_rocprof.json
+echo "kernel stats done"
+tools/pmc.sh c2 --spp 16 > /dev/null 2>&1; cp gpurun_out/pmc_c2/summary.txt $out/c2_pmc_spp16.txt
+tools/pmc.sh c5 --workload C5 --spp 32 > /dev/null 2>&1; cp gpurun_out/pmc_c5/summary.txt $out/c5_pmc_spp32.txt
+echo "pmc done"
+tools/phase_timing.sh C2 C4 C5 > $out/phase.log 2>&1; cp gpurun_out/phase_C2.json gpurun_out/phase_C4.json gpurun_out/phase_C5.json $out/
+echo "phase done"
+python3 -m pytest tests/test_gpu_bvhbuild.py tests/test_gpu_kdbuild.py -m gpu -q -s -k "report or built_on_the_device" > $out/builders.txt 2>&1
+python3 tools/stream_bench_real.py lowres 640 2 > $out/stream_vs_megakernel.json 2> /dev/null
+python3 tools/stream_bench_real.py hires 512 2 >> $out/stream_vs_megakernel.json 2> /dev/null
+echo "all done"
