@@ -110,8 +110,10 @@ typedef struct rt_params {
   uint32_t reserved[7];       /* [0]: samples of a pixel one wave integrates side by
                                  side (power of two <= 64; 0 = chosen from the grid
                                  size).  [1] bit 0: shade vertices sequentially instead
-                                 of through the wave's ray pool.  Neither changes the
-                                 result, only the schedule.                       */
+                                 of through the wave's ray pool.  [2] bit 0: the queue-
+                                 based (wavefront) integrator: path state and ray queues
+                                 in HBM, one trace launch per path depth.  None of them
+                                 changes the result, only the schedule.               */
 } rt_params;
 
 typedef struct rt_stats {

@@ -105,6 +105,10 @@ struct rt_ctx {
   // device-built BVH (rt_options.bvh_builder / RT_BVH_GPU): the float form of the nodes stays
   // on the device for rt_bvh_export
   float4* dNodesF = nullptr;
+  // path state + ray queues of the wavefront integrator (allocated on first use)
+  rtk::WfArgs wf{};
+  size_t wfCap = 0;
+  void* wfBlock = nullptr;
   uint32_t builder = RT_BVH_HOST;
   float buildMs = 0.f;
   uint32_t numCUs = 0;
@@ -291,6 +295,58 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   A.stackLevels = (levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels) + 1u;
   A.tileCounter = c->dTileCounter, A.numCUs = c->numCUs, A.waveWords = 0;
   const int e = c->evUsed % kEventPairs;
+  // rt_params.reserved[2] bit 0: the queue-based (wavefront) integrator — BVH direct lighting with
+  // at most 3 lights, like the pooled kernel; same frame bit for bit
+  if ((p->reserved[2] & 1u) && !p->use_photons && p->accel != RT_ACCEL_BRUTE && c->S.n_lights <= 3u) {
+    rt_ctx::GranList G;
+    rc = ensure_granules(c, p, p->rank, &G);
+    if (rc != RT_OK) return rc;
+    const size_t perSample = (size_t)G.n * 64u;
+    if (perSample == 0) {
+      HIP_TRY(hipEventRecord(c->ev[e][0], stream));
+      HIP_TRY(hipEventRecord(c->ev[e][1], stream));
+      c->evUsed++;
+      if (evIndex) *evIndex = e;
+      return RT_OK;
+    }
+    size_t batch = (4u << 20) / perSample;  // ~4 M paths per batch (1.1 GB of state + queues)
+    batch = batch < 1 ? 1 : batch > sppCount ? sppCount : batch;
+    const size_t P = batch * perSample;
+    if (P > c->wfCap) {
+      if (c->wfBlock) HIP_TRY(hipFree(c->wfBlock));
+      c->wfBlock = nullptr, c->wfCap = 0;
+      // rng 4, org 16, dir 16, key 8, nrm 16, pnt 16, col 48, rayO 64, rayD 64, res 32 = 284 B per path
+      const size_t bytes = P * 284 + 4096 + 2048 * sizeof(unsigned long long);
+      HIP_TRY(hipMalloc(&c->wfBlock, bytes));
+      char* q = static_cast<char*>(c->wfBlock);
+      auto take = [&](size_t n) {
+        char* r = q;
+        q += (n + 255) / 256 * 256;
+        return r;
+      };
+      rtk::WfArgs& W = c->wf;
+      W.rayO = reinterpret_cast<float4*>(take(P * 64)), W.rayD = reinterpret_cast<float4*>(take(P * 64));
+      W.col = reinterpret_cast<float4*>(take(P * 48));
+      W.org = reinterpret_cast<float4*>(take(P * 16)), W.dir = reinterpret_cast<float4*>(take(P * 16));
+      W.nrm = reinterpret_cast<float4*>(take(P * 16)), W.pnt = reinterpret_cast<float4*>(take(P * 16));
+      W.res = reinterpret_cast<uint2*>(take(P * 32)), W.key = reinterpret_cast<uint2*>(take(P * 8));
+      W.rng = reinterpret_cast<uint32_t*>(take(P * 4));
+      W.stripes = reinterpret_cast<unsigned long long*>(take(2048 * sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(W.stripes, 0, 2048 * sizeof(unsigned long long), stream));
+      c->wfCap = P;
+    }
+    rtk::WfArgs W = c->wf;
+    W.gran = G.d, W.nGran = G.n, W.width = p->width, W.height = p->height, W.spp = p->spp, W.seed = p->seed;
+    W.s0 = A.s0, W.s1 = A.s1, W.batch = (uint32_t)batch, W.nPaths = 0;
+    HIP_TRY(hipEventRecord(c->ev[e][0], stream));
+    hipError_t hw = rtk::launch_wavefront(c->S, W, p->mode, p->max_depth, dAccum, c->dCounters, c->dTileCounter, A.stackLevels,
+                                          c->numCUs, stream);
+    if (hw != hipSuccess) return fail(RT_ERR_HIP, "wavefront launch failed: %s", hipGetErrorString(hw));
+    HIP_TRY(hipEventRecord(c->ev[e][1], stream));
+    c->evUsed++;
+    if (evIndex) *evIndex = e;
+    return RT_OK;
+  }
   HIP_TRY(hipEventRecord(c->ev[e][0], stream));
   hipError_t he = rtk::launch_render(p->accel == RT_ACCEL_BRUTE, p->use_photons != 0, p->collect_stats != 0, c->S, A,
                                      dAccum, c->dCounters, stream);
@@ -424,6 +480,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->dCounters) (void)hipFree(c->dCounters);
   if (c->dTileCounter) (void)hipFree(c->dTileCounter);
   if (c->dNodesF) (void)hipFree(c->dNodesF);
+  if (c->wfBlock) (void)hipFree(c->wfBlock);
   for (auto& kv : c->granules)
     if (kv.second.d) (void)hipFree(kv.second.d);
   if (c->evReady)

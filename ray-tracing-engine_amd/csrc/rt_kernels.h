@@ -68,6 +68,25 @@ hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevSce
                          float4* accum, unsigned long long* counters, hipStream_t stream);
 hipError_t launch_resolve(uint32_t n_pixels, uint32_t spp, const float4* accum, const float* bg, float* out,
                           hipStream_t stream);
+// The wavefront integrator (wavefront.hip): path state of one batch, SoA in HBM
+struct WfArgs {
+  const uint32_t* gran;  // owned 8x8 granules (x8 | y8 << 16), row-major: path = (sample slot, granule, pixel)
+  uint32_t nGran, width, height, spp, seed;
+  uint32_t s0, s1;       // sample range still to do
+  uint32_t batch;        // samples per batch
+  uint32_t nPaths;       // paths of this batch (set by the launcher)
+  uint32_t* rng;         // [P] engine state
+  float4 *org, *dir;     // [P] current ray
+  uint2* key;            // [P] current hit {t bits, triangle id}; {~0, ~0}: the path has ended
+  float4 *nrm, *pnt;     // [P] vertex normal (+ mesh in w), point
+  float4* col;           // [3][P] vertex colours; col[0].w: primary hit, col[1].w: slot holds a sample
+  float4 *rayO, *rayD;   // [4P] ray queue
+  uint2* res;            // [4P] results
+  unsigned long long* stripes;  // [1024][2] striped ray counters (closest, shadow), zero between frames
+};
+hipError_t launch_wavefront(const DevScene& S, const WfArgs& W, uint32_t mode, uint32_t maxDepth, float4* accum,
+                            unsigned long long* counters, uint32_t* queueCounter, uint32_t stackLevels, uint32_t numCUs,
+                            hipStream_t stream);
 // ray queue in HBM -> results (wavefront stage T)
 hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const float4* rayD, uint32_t n, uint2* res,
                                uint32_t* counter, uint32_t stackLevels, uint32_t numCUs, hipStream_t stream);

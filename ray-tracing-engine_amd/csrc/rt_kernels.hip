@@ -1104,6 +1104,9 @@ __global__ __launch_bounds__(1024, 8) void k_trace_stream(DevScene S, const floa
   }
 }
 
+// ---------------------------------------------------------------- wavefront integrator
+#include "wavefront_kernels.h"
+
 // ---------------------------------------------------------------- frame assembly (multi-GPU)
 // A rank's owned 8x8-pixel granules, packed [granule][64 pixels] (row-major inside the
 // granule; slots outside the image are never read back), and the inverse on the rank

@@ -100,13 +100,14 @@ _host = None
 
 def make_params(width, height, spp, mode=MODE_PATH, seed=1, accel=ACCEL_BVH, max_depth=3, rng_mode=RNG_PIXEL,
                 use_photons=0, k=0, photons_requested=0, spp_begin=0, spp_count=0, rank=0, world=1, tile=8,
-                collect_stats=0, lanes_per_pixel=0, no_pool=False):
+                collect_stats=0, lanes_per_pixel=0, no_pool=False, wavefront=False):
     p = Params()
     p.width, p.height, p.spp, p.mode, p.max_depth, p.seed = width, height, spp, mode, max_depth, seed
     p.rng_mode, p.accel, p.use_photons, p.k, p.photons_requested = rng_mode, accel, use_photons, k, photons_requested
     p.spp_begin, p.spp_count, p.rank, p.world, p.tile, p.collect_stats = spp_begin, spp_count, rank, world, tile, collect_stats
     p.reserved[0] = lanes_per_pixel  # 0 = automatic; power of two <= 64: samples of a pixel a wave runs side by side
     p.reserved[1] = 1 if no_pool else 0  # schedule only: sequential shading instead of the wave's ray pool
+    p.reserved[2] = 1 if wavefront else 0  # schedule only: the queue-based integrator
     return p
 
 
