@@ -99,6 +99,19 @@ class FrameAssembler:
     def assemble(self, accum, stream=0):
         if self.world <= 1:
             return accum
+        if getattr(self, "fallback", False):
+            return reduce_frame(accum, dst=0)
+        try:
+            return self._gather(accum, stream)
+        except RuntimeError as e:  # a backend without gather: the reference exchange gives the same frame
+            if getattr(self, "calls", 0) > 0:
+                raise
+            import sys
+            sys.stderr.write("FrameAssembler: gather failed (%s); falling back to the full-frame SUM reduce\n" % e)
+            self.fallback = True
+            return reduce_frame(accum, dst=0)
+
+    def _gather(self, accum, stream):
         if self.cuda:
             self.ctx.pack_owned(self.params, accum.data_ptr(), self.packed.data_ptr(), stream)
             send = self.packed if self.stage_dev != "cpu" else self.packed.cpu()
@@ -107,6 +120,7 @@ class FrameAssembler:
             self.packed[: len(ix)] = accum.view(-1, 4)[ix]
             send = self.packed
         dist.gather(send, self.recv if self.rank == 0 else None, dst=0)
+        self.calls = getattr(self, "calls", 0) + 1
         if self.rank == 0:
             for r in range(1, self.world):
                 if self.cuda:
