@@ -1,7 +1,7 @@
 // rt_kernels.hip — gfx950 kernels of the path-tracing hot path.
 //
 // Execution model (wave64, CDNA4):
-//   * one workgroup = one wave; one lane = one (pixel, sample) pair: a wave integrates
+//   * one lane = one (pixel, sample) pair in every render kernel: a wave integrates
 //     S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side and the
 //     pixel's owner lane adds them in sample order, so every pixel's float sum is formed
 //     in exactly the order the reference forms it (Renderer.cpp:219-258) whatever S, the
@@ -12,8 +12,11 @@
 //     triangle records 48 B (3 x dwordx4);
 //   * the photon k-NN keeps its k-heap in LDS ([slot][thread]) and re-uses the
 //     traversal stack region for the kd-tree's per-level split distances;
-//   * no inter-workgroup communication, no barriers: every wave is independent,
-//     counters leave through one atomic per wave.
+//   * the pooled integrator (BVH direct lighting) runs as ONE persistent workgroup of 16
+//     waves per CU: its LDS holds the whole BVH when it fits plus every wave's private
+//     stack and ray pool, waves draw wave tiles from a global counter; after the tree copy
+//     no wave ever synchronises with another (wave-scope fences only), counters leave
+//     through one atomic per wave.
 // Built with -ffp-contract=off (bit parity with the x86-64 oracle, no FMA).
 #include <hip/hip_runtime.h>
 
