@@ -2,7 +2,7 @@
 """k_trace_stream on the REAL secondary rays of a frame (dumped by the oracle in casting
 order), queued the way a wavefront integrator would queue them: one queue per path depth,
 [vertex][3 shadow rays + bounce ray].  Prints Grays/s per stage and overall, next to the
-megakernel's whole-frame rate on the same frame.  usage: stream_bench_real.py [scene] [w] [spp]"""
+megakernel's whole-frame rate on the same frame.  usage: diag_stream_vs_fused.py [scene] [w] [spp]"""
 import json
 import os
 import sys
@@ -10,6 +10,8 @@ import time
 
 import numpy as np
 
+# (lives under tests/ because it uses the ORACLE to dump the frame's rays: test infrastructure,
+# never imported by the product or by tools/)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracing-engine_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -53,6 +53,15 @@ def test_no_device_is_a_loud_error_not_a_fallback():
     import numpy as np
     with pytest.raises(pyrt.RtError):
         pyrt.unit(pyrt.UNIT_SINF, np.zeros(4, np.float32))
+    with pytest.raises(pyrt.RtError) as e:
+        pyrt.Group(s, [0, 0])
+    assert e.value.code == 2
+    with pytest.raises(pyrt.RtError) as e:
+        pyrt.kd_order_device(np.zeros((8, 3), np.float32))
+    assert e.value.code == 2
+    with pytest.raises(pyrt.RtError) as e:
+        pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE)
+    assert e.value.code == 2
 
 
 def test_scene_rejects_unknown_kind_and_missing_mesh(tmp_path):

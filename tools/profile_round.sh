@@ -23,6 +23,6 @@ echo "pmc done"
 tools/phase_timing.sh C2 C4 C5 > $out/phase.log 2>&1; cp gpurun_out/phase_C2.json gpurun_out/phase_C4.json gpurun_out/phase_C5.json $out/
 echo "phase done"
 python3 -m pytest tests/test_gpu_bvhbuild.py tests/test_gpu_kdbuild.py -m gpu -q -s -k "report or built_on_the_device" > $out/builders.txt 2>&1
-python3 tools/stream_bench_real.py lowres 640 2 > $out/stream_vs_megakernel.json 2> /dev/null
-python3 tools/stream_bench_real.py hires 512 2 >> $out/stream_vs_megakernel.json 2> /dev/null
+python3 tests/diag_stream_vs_fused.py lowres 640 2 > $out/stream_vs_megakernel.json 2> /dev/null
+python3 tests/diag_stream_vs_fused.py hires 512 2 >> $out/stream_vs_megakernel.json 2> /dev/null
 echo "all done"
