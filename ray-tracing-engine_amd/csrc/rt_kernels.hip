@@ -1334,6 +1334,17 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
 }
 
 // ---------------------------------------------------------------- launchers
+// Dynamic LDS beyond 64 KiB must be allowed per kernel AND per device (one process may drive
+// several devices: rt_group): `done` is the caller's per-kernel bit mask of devices already set.
+template <class K>
+static void allow_big_lds(K kernel, unsigned long long& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+  if (done & (1ull << dev)) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done |= 1ull << dev;
+}
+
 // LDS plan of the persistent pooled kernel: W waves per workgroup (one workgroup per CU),
 // topK tree-top nodes in front of W private regions of waveWords each.  160 KiB per CU.
 struct PersistPlan {
@@ -1377,14 +1388,10 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
       if (e != hipSuccess) return e;
       const uint32_t perCU = P.waves;                                    // waves one workgroup brings
       const uint32_t wgs = (blocks + perCU - 1) / perCU < A.numCUs ? (blocks + perCU - 1) / perCU : A.numCUs;
-      // dynamic LDS beyond 64 KiB must be allowed per kernel
 #define RT_LAUNCH_PERSIST(ST, LTV)                                                                                      \
   do {                                                                                                                  \
-    static bool once = false;                                                                                           \
-    if (!once)                                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_persist<ST, LTV>),                              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),                                \
-          once = true;                                                                                                  \
+    static unsigned long long done = 0;                                                                                 \
+    allow_big_lds(&k_render_persist<ST, LTV>, done);                                                                    \
     hipLaunchKernelGGL((k_render_persist<ST, LTV>), dim3(wgs), dim3(64u * P.waves), P.ldsBytes, stream, S2, A2, accum,  \
                        counters);                                                                                       \
   } while (0)
@@ -1451,12 +1458,12 @@ hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const floa
   static const uint32_t perCU = getenv("RT_STREAM_WGS") ? (uint32_t)atoi(getenv("RT_STREAM_WGS")) : 2u;
   wgs = wgs < perCU * numCUs ? wgs : perCU * numCUs;
   if (S2.topK >= S.n_nodes && S2.topK) {
-    static bool once = false;
-    if (!once) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_stream<LT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), once = true;
+    static unsigned long long done = 0;
+    allow_big_lds(&k_trace_stream<LT_ALL>, done);
     hipLaunchKernelGGL((k_trace_stream<LT_ALL>), dim3(wgs), dim3(64u * wpw), ldsBytes, stream, S2, rayO, rayD, n, res, counter, stackLevels);
   } else {
-    static bool once = false;
-    if (!once) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_stream<LT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), once = true;
+    static unsigned long long done = 0;
+    allow_big_lds(&k_trace_stream<LT_NONE>, done);
     hipLaunchKernelGGL((k_trace_stream<LT_NONE>), dim3(wgs), dim3(64u * wpw), ldsBytes, stream, S2, rayO, rayD, n, res, counter, stackLevels);
   }
   return hipGetLastError();
