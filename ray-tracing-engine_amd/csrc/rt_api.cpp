@@ -96,6 +96,7 @@ struct rt_ctx {
   TileKey tileKey;
   unsigned long long* dCounters = nullptr;
   uint32_t* dTileCounter = nullptr;  // work queue head of the persistent render kernel
+  uint32_t* dSsOver = nullptr;       // short-stack overflow columns (deep trees only)
   // owned-granule lists of the ranks of a tile-sharded frame (multi-GPU assembly), by key
   struct GranList {
     uint32_t* d = nullptr;
@@ -294,6 +295,7 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   // (+1: row 0 of a lane's stack is the TERM sentinel, rt_kernels.hip Trav)
   A.stackLevels = (levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels) + 1u;
   A.tileCounter = c->dTileCounter, A.numCUs = c->numCUs, A.waveWords = 0;
+  A.ssOver = c->dSsOver;
   const int e = c->evUsed % kEventPairs;
   // rt_params.reserved[2] bit 0: the queue-based (wavefront) integrator — BVH direct lighting with
   // at most 3 lights, like the pooled kernel; same frame bit for bit
@@ -445,7 +447,7 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
   S.stealT = getenv("RT_STEALT") ? atoi(getenv("RT_STEALT")) : 8;
   S.refillT = getenv("RT_REFILLT") ? atoi(getenv("RT_REFILLT")) : 24;  // measured C2: 1 -> 15.9, 8 -> 16.0, 16 -> 16.1, 32 -> 16.2 Grays/s
   S.phPos = S.phDir = nullptr;
-  S.topK = 0;
+  S.topK = 0, S.ssRows = 0, S.ssOvRows = 0, S.ssOver = nullptr;
   S.cam = sc->camera;
   {
     int cus = 0;
@@ -453,6 +455,13 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
     if (hipMalloc(reinterpret_cast<void**>(&c->dTileCounter), sizeof(uint32_t)) != hipSuccess) {
       rt_destroy(c);
       return fail(RT_ERR_HIP, "tile counter allocation failed");
+    }
+    // trees deeper than the short stack's 12 LDS entries: overflow columns in HBM, one per lane of
+    // every wave the persistent kernel can have in flight (numCUs x 16 waves x 32 rows x 256 B)
+    if (c->bvh.maxDepth > 1 &&
+        hipMalloc(reinterpret_cast<void**>(&c->dSsOver), (size_t)c->numCUs * 16u * 32u * 64u * sizeof(uint32_t)) != hipSuccess) {
+      rt_destroy(c);
+      return fail(RT_ERR_HIP, "short-stack overflow allocation failed");
     }
   }
   if (hipMalloc(reinterpret_cast<void**>(&c->dCounters), RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
@@ -479,6 +488,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->dTiles) (void)hipFree(c->dTiles);
   if (c->dCounters) (void)hipFree(c->dCounters);
   if (c->dTileCounter) (void)hipFree(c->dTileCounter);
+  if (c->dSsOver) (void)hipFree(c->dSsOver);
   if (c->dNodesF) (void)hipFree(c->dNodesF);
   if (c->wfBlock) (void)hipFree(c->wfBlock);
   for (auto& kv : c->granules)

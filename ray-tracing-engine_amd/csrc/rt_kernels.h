@@ -43,6 +43,10 @@ struct DevScene {
   uint32_t n_tris, n_nodes, n_lights, n_photons;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
   uint32_t topK;           // node records [0, topK) are LDS-resident in the persistent kernel (set per launch)
+  // short stack (pooled persistent kernel on deep trees; set per launch)
+  uint32_t ssRows;         // stack entries kept in LDS (0 = the whole stack is in LDS)
+  uint32_t ssOvRows;       // rows of a lane's overflow column
+  uint32_t* ssOver;        // [wave slot][ssOvRows][64] overflow columns in HBM
   float originBound;       // k_trace: rays starting farther out run the exhaustive loop (rtbvh::Built)
   uint32_t leafT;          // Trav::round leaves its descent when fewer lanes than this still descend
   uint32_t refillT;        // vertex_pool hands out rays once this many workers are free
@@ -62,6 +66,7 @@ struct RenderArgs {
   uint32_t* tileCounter;  // next wave tile to hand out (zeroed before the launch)
   uint32_t waveWords;     // LDS words per wave (stack levels x 64 + pool), set by the launcher
   uint32_t numCUs;        // workgroups to launch (one per CU)
+  uint32_t* ssOver;       // short-stack overflow buffer of the context (numCUs x 16 waves x 32 rows x 64 words)
 };
 
 hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,

@@ -35,6 +35,7 @@ constexpr int STACK = rtbvh::kMaxDepth;  // 32 words per lane
 constexpr int KMAX = RTK_KMAX;           // photon heap capacity per lane
 
 struct Lds {
+  uint32_t* over = nullptr;  // short stack: this lane's overflow column in HBM
   uint32_t* stack;  // [STACK][BLOCK] this thread's column: stack[level * BLOCK]
   uint2* heap;      // [KMAX][BLOCK] {distance bits, photon index}
 };
@@ -134,11 +135,18 @@ constexpr int TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_MIXED = 2;  // MIXED: per-lan
 // LT: where node records live.  LT_NONE: HBM/L2 through the vector L1; LT_TOP: records
 // [0, S.topK) in LDS (g_lds), the rest in HBM/L2; LT_ALL: the whole tree in LDS.
 constexpr int LT_NONE = 0, LT_TOP = 1, LT_ALL = 2;
+// + LT_SS: SHORT STACK.  Only the first S.ssRows entries of a lane's stack live in LDS; deeper
+// ones (rare: a ray's pending far children seldom exceed a dozen) spill to a per-lane column in
+// HBM.  A 21-level tree then costs a wave 13 rows of LDS instead of 22, which is what makes room
+// for the top of a big tree beside 16 waves.
+constexpr int LT_SS = 4;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
 
-template <int MODE, int LT = LT_NONE>
+template <int MODE, int LTX = LT_NONE>
 struct Trav {
+  static constexpr int LT = LTX & 3;
+  static constexpr bool SS = (LTX & LT_SS) != 0;
   f3 o, d, inv, oi;
   float best;
   uint32_t bestId;
@@ -148,6 +156,10 @@ struct Trav {
   // so no step ever tests for emptiness or clamps an index)
   uint32_t* top;
   uint32_t* base;
+  // short stack (SS): entries beyond row S.ssRows live at over[i * BLOCK], i < ov
+  uint32_t* over;
+  uint32_t* limit;  // base + ssRows * BLOCK: the last LDS row
+  int ov;
   int32_t cur;
   HitRec hit;
   // pool mode (TRAV_MIXED): several lanes may walk disjoint subtrees of ONE ray
@@ -160,8 +172,16 @@ struct Trav {
   unsigned long long* sharedKey;
   uint32_t pj;
 
-  RT_DEV int depth() const { return (int)(top - base) / BLOCK; }  // entries on the stack (live lanes only)
-  RT_DEV void idle(uint32_t* stack) { cur = TERM, found = false, base = top = stack, stolen = 0, shared = false; }
+  RT_DEV int depth() const { return (int)(top - base) / BLOCK + (SS ? ov : 0); }  // entries on the stack (live lanes only)
+  RT_DEV void idle(uint32_t* stack, uint32_t* overflow = nullptr, uint32_t ssRows = 0) {
+    cur = TERM, found = false, base = top = stack, stolen = 0, shared = false;
+    over = overflow, limit = stack + ssRows * BLOCK, ov = 0;
+  }
+  RT_DEV uint32_t peek() const { return (SS && ov) ? over[(ov - 1) * BLOCK] : *top; }
+  RT_DEV void pop() {
+    if (SS && ov) --ov;
+    else top -= BLOCK;
+  }
   RT_DEV void start(f3 o_, f3 d_, float invScale) {
     o = o_, d = d_;
     const f3 i1 = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
@@ -170,6 +190,7 @@ struct Trav {
     inv = mk(i1.x * invScale, i1.y * invScale, i1.z * invScale);
     best = 3.402823466e+38f;  // numeric_limits<float>::max(), RayTracer.h:30
     bestId = 0, found = false, top = base, cur = 0, stolen = 0, shared = false;
+    ov = 0;
     *base = (uint32_t)TERM;
     // A ray with a NaN component cannot hit anything: Ray.cpp:9-24 then yields NaN u
     // or v for every triangle and every comparison fails (hemisphere samples are NaN
@@ -207,7 +228,7 @@ struct Trav {
       PHC(PH_N_STEPS);
       // the entry a miss would pop, fetched with the node (its latency hides behind the
       // node's; a read in the divergent pop branch made every step wait for LDS)
-      const int32_t below = (int32_t)*top;
+      const int32_t below = (int32_t)peek();
       const int2 ch = make_int2((int)b.z, (int)b.w);
       if (STATS) {
         st.nodes++;
@@ -221,9 +242,23 @@ struct Trav {
       // both children were hit)
       const bool both = h0 && h1, any = h0 || h1;
       const bool takeY = h1 && (!h0 || t1 < t0);  // which child to enter (lane-mask logic, no selects)
-      top[BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
-      cur = any ? (takeY ? ch.y : ch.x) : below;
-      top += both ? BLOCK : any ? 0 : -BLOCK;  // (a lane that pops the sentinel is dead until start())
+      if (SS) {
+        const bool full = top == limit;  // the LDS rows are used up: this entry goes to HBM
+        const uint32_t far = (uint32_t)(takeY ? ch.x : ch.y);
+        if (full) over[ov * BLOCK] = far;
+        else top[BLOCK] = far;
+        cur = any ? (takeY ? ch.y : ch.x) : below;
+        if (both) {
+          if (full) ++ov;
+          else top += BLOCK;
+        } else if (!any) {
+          pop();
+        }
+      } else {
+        top[BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
+        cur = any ? (takeY ? ch.y : ch.x) : below;
+        top += both ? BLOCK : any ? 0 : -BLOCK;  // (a lane that pops the sentinel is dead until start())
+      }
       // leave the descent early once only a few lanes are still descending: they
       // sit out one leaf phase (masked) instead of making everyone else wait for them
       // (only when the lanes that would otherwise wait clearly outnumber them: in the
@@ -247,8 +282,8 @@ struct Trav {
         const float4* q = S.tris + 3 * (size_t)(first + i);
         stop = test_record<STATS>(q[0], q[1], q[2], st);
       }
-      cur = stop ? TERM : (int32_t)*top;
-      top -= BLOCK;
+      cur = stop ? TERM : (int32_t)peek();
+      pop();
     }
     PH(PH_LEAF);
   }
@@ -325,9 +360,10 @@ struct Trav {
 //                only uses the bool)
 // `on` = this lane has a ray; lanes without one still take part in the wave loop.
 template <bool ANY, bool STATS, int LT = LT_NONE>
-RT_DEV bool traverse(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
+RT_DEV bool traverse(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st,
+                     uint32_t* over = nullptr) {
   Trav<ANY ? TRAV_ANY : TRAV_CLOSEST, LT> T;
-  T.idle(stack);
+  T.idle(stack, over, S.ssRows);
   if (on) T.start(o, d, S.invBoxScale);
   PH(PH_SETUP);
   while (__ballot(T.live()) != 0) {
@@ -361,9 +397,10 @@ RT_DEV bool brute(const DevScene& S, f3 o, f3 d, HitRec& hit, LaneStats& st) {
 
 // `on`: lanes without a ray pass false (wave-uniform call sites, no early exits).
 template <bool BRUTE, bool ANY, bool STATS, int LT = LT_NONE>
-RT_DEV bool cast(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
+RT_DEV bool cast(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st,
+                 uint32_t* over = nullptr) {
   if (BRUTE) return on && brute<ANY, STATS>(S, o, d, hit, st);
-  return traverse<ANY, STATS, LT>(S, on, o, d, stack, hit, st);
+  return traverse<ANY, STATS, LT>(S, on, o, d, stack, hit, st, over);
 }
 
 // Renderer.cpp:274-277 dotArr: (w*a + u*b) + v*c per component
@@ -636,7 +673,8 @@ static_assert(VP_KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 
 template <bool STATS, int LT>
 RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
-                      f3 point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
+                      f3 point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
+                      uint32_t* over = nullptr) {
   const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
   float* fp = reinterpret_cast<float*>(pool);
   // 32 words: rank -> pixel lane (64 bytes) while rays are handed out; then rank -> victim
@@ -675,7 +713,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   const uint32_t kinds = nl + (bounce ? 1u : 0u), R = n * kinds;
   uint32_t head = 0, myK = 0, myJ = 0;
   Trav<TRAV_MIXED, LT> T;
-  T.idle(stack);
+  T.idle(stack, over, S.ssRows);
   T.sharedKey = keys, T.pj = 0;
   uint32_t* stackBase = stack - lane;
   for (;;) {
@@ -716,7 +754,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       uint16_t* list16 = reinterpret_cast<uint16_t*>(list);
       uint32_t given = 0;
       for (int pass = 0; pass < 4; pass++) {
-        const bool canGive = T.live() && T.depth() > T.stolen;
+        // (short stack: only the entries resident in LDS can be handed over)
+        const bool canGive = T.live() && T.depth() > T.stolen && (!(LT & LT_SS) || T.stolen < (int)S.ssRows);
         const uint64_t vmask = __ballot(canGive);
         if (vmask == 0 || given >= (uint32_t)nIdle) break;
         if (canGive) {
@@ -873,7 +912,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
       // primary ray (coherent: traced in lock step), then one pool per vertex
       HitRec h;
       if (alive) st.closest++;
-      const bool hit0 = cast<false, false, STATS, LT>(S, alive, o, d, L.stack, h, st);
+      const bool hit0 = cast<false, false, STATS, LT>(S, alive, o, d, L.stack, h, st, L.over);
       if (alive && !hit0) primary = false, alive = false;
       for (int depth = 0; depth < nvert; depth++) {
         if (__ballot(alive) == 0) break;
@@ -886,7 +925,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
         // stream ends there — the pool only draws it when a bounce ray follows)
         HitRec nh;
         bool nfound;
-        const f3 c = vertex_pool<STATS, LT>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
+        const f3 c = vertex_pool<STATS, LT>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st, L.over);
         if (alive) {
           if (depth == 0) c0 = c;
           else if (depth == 1) c1 = c;
@@ -988,7 +1027,8 @@ __global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs 
   }
   __syncthreads();  // the only workgroup-wide barrier
   uint32_t* mine = g_lds + 8u * S.topK + wv * A.waveWords;
-  const Lds L = carve_lds<false>(mine, A.stackLevels, 0);
+  Lds L = carve_lds<false>(mine, A.stackLevels, 0);
+  if (LT & LT_SS) L.over = S.ssOver + ((size_t)blockIdx.x * (blockDim.x >> 6) + wv) * S.ssOvRows * BLOCK + lane;
   uint32_t* pool = mine + A.stackLevels * BLOCK;
   float* ex = reinterpret_cast<float*>(pool);
   LaneStats st;
@@ -1349,6 +1389,7 @@ static void allow_big_lds(K kernel, unsigned long long& done) {
 // topK tree-top nodes in front of W private regions of waveWords each.  160 KiB per CU.
 struct PersistPlan {
   uint32_t waves, topK, waveWords, ldsBytes;
+  uint32_t ssRows;  // > 0: short stack (that many entries in LDS, the rest in HBM)
 };
 static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   const uint32_t total = 160u * 1024u / 4u - 64u;  // words (a little room for the diagnostic build's statics)
@@ -1360,7 +1401,23 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   // on every scene — and a PARTIAL top (LT_TOP: a branch per node step) gave C4 -2 %, while
   // the whole tree in LDS (LT_ALL, no branch) gives C2 +5.6 %.  So: 16 waves; the tree goes
   // to LDS only if all of it fits beside them.  RT_PERSIST_WAVES / RT_TOPK override.
-  PersistPlan best{0, 0, waveWords, 0};
+  PersistPlan best{0, 0, waveWords, 0, 0};
+  // SHORT STACK (RT_SS=1; opt-in): 12 entries per lane in LDS, deeper ones in HBM, so that 16
+  // waves leave room for the top of a deep tree (the most-visited ~1,100 nodes of a 21-level one).
+  // Measured on the 1 M-triangle scene: the spill bookkeeping costs 11 %, the
+  // partial LDS top another 6 % — the full-depth stack (which already fits 16 waves) stays the default.
+  static const int ssEnv = getenv("RT_SS") ? atoi(getenv("RT_SS")) : -1;
+  const bool deep = false;
+  static const int ssRowsEnv = getenv("RT_SS_ROWS") ? atoi(getenv("RT_SS_ROWS")) : 12;  // (tests force it small)
+  const uint32_t ssRowsWanted = ssRowsEnv < 1 ? 1u : (uint32_t)ssRowsEnv;
+  if (A.ssOver && (ssEnv >= 0 ? ssEnv != 0 : deep) && A.stackLevels - 1u > ssRowsWanted) {
+    const uint32_t rows = ssRowsWanted, ww = (rows + 1u) * BLOCK + VP_WORDS;
+    uint32_t w2 = wEnv > 0 ? (uint32_t)wEnv : 16u;
+    uint32_t k2 = (total - w2 * ww) / 8u;
+    k2 = k2 < cap ? k2 : cap;
+    if (kEnv >= 0) k2 = (uint32_t)kEnv < k2 ? (uint32_t)kEnv : k2;
+    return PersistPlan{w2, k2, ww, 4u * (8u * k2 + w2 * ww), rows};
+  }
   uint32_t w = wEnv > 0 ? (uint32_t)wEnv : 16u;
   while (w > 1u && w * waveWords > total) --w;
   if (w * waveWords > total) return best;
@@ -1368,7 +1425,7 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   k = k < cap ? k : cap;
   if (kEnv >= 0) k = (uint32_t)kEnv < k ? (uint32_t)kEnv : k;
   else if (k < S.n_nodes) k = 0;
-  best = PersistPlan{w, k, waveWords, 4u * (8u * k + w * waveWords)};
+  best = PersistPlan{w, k, waveWords, 4u * (8u * k + w * waveWords), 0};
   return best;
 }
 
@@ -1384,6 +1441,10 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
       DevScene S2 = S;
       RenderArgs A2 = A;
       S2.topK = P.topK, A2.waveWords = P.waveWords;
+      if (P.ssRows) {
+        S2.ssRows = P.ssRows, S2.ssOver = A.ssOver, S2.ssOvRows = 32u;
+        A2.stackLevels = P.ssRows + 1u;
+      }
       hipError_t e = hipMemsetAsync(A.tileCounter, 0, sizeof(uint32_t), stream);
       if (e != hipSuccess) return e;
       const uint32_t perCU = P.waves;                                    // waves one workgroup brings
@@ -1396,7 +1457,15 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
                        counters);                                                                                       \
   } while (0)
       const int lt = P.topK == 0 ? LT_NONE : P.topK >= S.n_nodes ? LT_ALL : LT_TOP;
-      if (stats) {
+      if (P.ssRows) {
+        if (stats) {
+          if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP | LT_SS);
+          else RT_LAUNCH_PERSIST(true, LT_NONE | LT_SS);
+        } else {
+          if (lt == LT_TOP) RT_LAUNCH_PERSIST(false, LT_TOP | LT_SS);
+          else RT_LAUNCH_PERSIST(false, LT_NONE | LT_SS);
+        }
+      } else if (stats) {
         if (lt == LT_ALL) RT_LAUNCH_PERSIST(true, LT_ALL);
         else if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP);
         else RT_LAUNCH_PERSIST(true, LT_NONE);
