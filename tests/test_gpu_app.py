@@ -102,6 +102,24 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
         assert 0 < one["roofline"]["frac"] <= 1 and 0 < one["roofline"]["hbm"]["frac"] <= 1
 
 
+def test_bench_spawns_its_own_launcher(tmp_path):
+    """`python bench.py --gpus N` with no launcher in the environment starts
+    torch.distributed.run itself (as a child, before touching the GPU) and rank 0 still prints the
+    one JSON line.  Rehearsed with 3 gloo ranks sharing this GPU."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RT_DIST_BACKEND="gloo", RT_SHARE_GPU="1", MASTER_PORT="29733")
+    r = subprocess.run([sys.executable, os.path.join(pyrt.ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
+                        "--workload", "C1"], capture_output=True, text=True, env=env, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["config"]["rays_per_frame"] == 5526901 and d["value"] > 0
+    assert "owned tiles gathered" in d["config"]["parallelism"]
+
+
 def test_progressive_update_ppm_matches_the_reference_semantics(tmp_path):
     """-progress 1: an update.ppm after every pass (Renderer.cpp:261-269).  The final
     image is the one-launch image, and stopping after pass j gives the j-sample estimate
