@@ -366,7 +366,22 @@ extern "C" {
 int rt_abi_version(void) { return RT_ABI_VERSION; }
 const char* rt_last_error(void) { return g_err.c_str(); }
 
-int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
+}  // extern "C"
+
+namespace {
+// rt_create with an optional host-built tree to copy instead of building one (rt_group: every
+// device gets the same tree, built once)
+int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Built* prebuilt, rt_ctx** out);
+}  // namespace
+
+extern "C" {
+
+int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) { return create_ctx(sc, opt, nullptr, out); }
+
+}  // extern "C"
+
+namespace {
+int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Built* prebuilt, rt_ctx** out) {
   if (!sc || !out) return fail(RT_ERR_INVALID, "scene/out is null");
   *out = nullptr;
   if (!sc->vertex_pos || !sc->vertex_nrm || !sc->tri_vtx || !sc->mesh_tri_begin || !sc->mesh_vtx_begin ||
@@ -388,6 +403,8 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
     if (gpuBuild) {
       plan = rtbvh::planScene(*sc, opt ? opt->bvh_leaf_max : 0);
       c->bvh.leafMax = plan.leafMax, c->bvh.pad = plan.pad, c->bvh.originBound = plan.originBound, c->bvh.boxScale = plan.boxScale;
+    } else if (prebuilt) {
+      c->bvh = *prebuilt;
     } else {
       rtbvh::build(*sc, opt ? opt->bvh_leaf_max : 0, c->bvh);
     }
@@ -478,6 +495,9 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) {
   *out = c;
   return RT_OK;
 }
+}  // namespace
+
+extern "C" {
 
 void rt_destroy(rt_ctx* c) {
   if (!c) return;
@@ -1069,7 +1089,9 @@ int rt_group_create(const rt_scene_desc* scene, const int32_t* devices, uint32_t
     if (opt) o = *opt;
     o.device = devices[r];
     rt_ctx* c = nullptr;
-    int rc = rt_create(scene, &o, &c);
+    // the host tree is built by the first context and copied by the others
+    const rtbvh::Built* shared = (r > 0 && g->ctx[0]->builder == RT_BVH_HOST) ? &g->ctx[0]->bvh : nullptr;
+    int rc = create_ctx(scene, &o, shared, &c);
     hipStream_t s = nullptr;
     hipEvent_t e = nullptr;
     if (rc == RT_OK && (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
