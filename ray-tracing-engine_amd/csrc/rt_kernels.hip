@@ -208,7 +208,12 @@ struct Trav {
     uint32_t statWait = 0, statIdle = 0;
     if (STATS) statWait = (uint32_t)__popcll(__ballot(cur < 0 && cur != TERM)), statIdle = (uint32_t)__popcll(__ballot(cur == TERM));
     PHC(PH_N_ROUNDS);
-    while (cur >= 0) {
+    // The loop is WAVE-UNIFORM (a ballot decides, every lane leaves together) and the step a
+    // plain predicated region inside it: with the lane condition as the loop condition the
+    // compiler keeps per-lane exit masks (20 scalar instructions + 4 branches per step, and a
+    // wave issues one instruction of ANY kind per 4 cycles).
+    if (__ballot(cur >= 0)) for (;;) {
+     if (cur >= 0) {
       // 32-B packed node: 12 x f16 planes + 2 refs (32-bit byte offset from a uniform base:
       // the load takes the base from SGPRs)
       uint4 a, b;
@@ -241,7 +246,7 @@ struct Trav {
       // the far child is stored unconditionally (the slot is simply not claimed unless
       // both children were hit)
       const bool both = h0 && h1, any = h0 || h1;
-      const bool takeY = h1 && (!h0 || t1 < t0);  // which child to enter (lane-mask logic, no selects)
+      const bool takeY = h1 & (!h0 | (t1 < t0));  // which child to enter (lane-mask logic: no selects, no branch)
       if (SS) {
         const bool full = top == limit;  // the LDS rows are used up: this entry goes to HBM
         const uint32_t far = (uint32_t)(takeY ? ch.x : ch.y);
@@ -264,6 +269,7 @@ struct Trav {
       // (only when the lanes that would otherwise wait clearly outnumber them: in the
       // tail of a pool, with a handful of live rays, a round must not shrink to one step)
       // (desc < leafT and 3 * desc < live0, folded into one threshold)
+     }
       if (__popcll(__ballot(cur >= 0)) < exitBelow) break;
     }
     PH(PH_DESCENT);
