@@ -634,10 +634,10 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
     const Node& n = out.nodes[i];
     Node16& q = out.nodes16[i];
     for (int a = 0; a < 3; ++a) {
-      q.lo0[a] = toHalfDirected(n.lo0[a] * out.boxScale, false), q.hi0[a] = toHalfDirected(n.hi0[a] * out.boxScale, true);
-      q.lo1[a] = toHalfDirected(n.lo1[a] * out.boxScale, false), q.hi1[a] = toHalfDirected(n.hi1[a] * out.boxScale, true);
-      if (halfToFloat(q.lo0[a]) > n.lo0[a] * out.boxScale || halfToFloat(q.hi0[a]) < n.hi0[a] * out.boxScale ||
-          halfToFloat(q.lo1[a]) > n.lo1[a] * out.boxScale || halfToFloat(q.hi1[a]) < n.hi1[a] * out.boxScale)
+      q.box0[2 * a] = toHalfDirected(n.lo0[a] * out.boxScale, false), q.box0[2 * a + 1] = toHalfDirected(n.hi0[a] * out.boxScale, true);
+      q.box1[2 * a] = toHalfDirected(n.lo1[a] * out.boxScale, false), q.box1[2 * a + 1] = toHalfDirected(n.hi1[a] * out.boxScale, true);
+      if (halfToFloat(q.box0[2 * a]) > n.lo0[a] * out.boxScale || halfToFloat(q.box0[2 * a + 1]) < n.hi0[a] * out.boxScale ||
+          halfToFloat(q.box1[2 * a]) > n.lo1[a] * out.boxScale || halfToFloat(q.box1[2 * a + 1]) < n.hi1[a] * out.boxScale)
         throw std::runtime_error("internal error: packed box does not contain the float box");
     }
     q.child[0] = n.child[0], q.child[1] = n.child[1];

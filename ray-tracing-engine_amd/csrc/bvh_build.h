@@ -40,8 +40,11 @@ static_assert(sizeof(Node) == 64, "node record must be 64 bytes");
 // lane pulls through the CU's 64 B/clk L1 data path per traversal step — the unit
 // that bounds this kernel on cache-resident scenes.  boxScale is a power of two
 // (exact) chosen so that |coordinate * boxScale| <= 32768.
+// Per child the planes are stored as (lo, hi) PAIRS per axis — x, y, z — so that one 32-bit
+// word holds both planes of an axis: the traversal orders them along the ray with one rotate
+// (rt_kernels.hip order_planes) instead of a min and a max per axis.
 struct alignas(16) Node16 {  // 32 B
-  uint16_t lo0[3], hi0[3], lo1[3], hi1[3];
+  uint16_t box0[6], box1[6];  // box[2 * axis] = lo, box[2 * axis + 1] = hi
   int32_t child[2];
 };
 static_assert(sizeof(Node16) == 32, "packed node record must be 32 bytes");

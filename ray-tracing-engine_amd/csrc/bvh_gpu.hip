@@ -287,12 +287,12 @@ __global__ void k_level_emit(const WorkItem* __restrict__ items, uint32_t count,
   nodesF[4 * (size_t)i + 1] = make_float4(B0.hy, B0.hz, B1.lx, B1.ly);
   nodesF[4 * (size_t)i + 2] = make_float4(B1.lz, B1.hx, B1.hy, B1.hz);
   nodesF[4 * (size_t)i + 3] = make_float4(__int_as_float(child[0]), __int_as_float(child[1]), 0.f, 0.f);
-  // packed form (rtbvh::Node16: lo0[3] hi0[3] lo1[3] hi1[3] as binary16 of coordinate x boxScale, outward)
+  // packed form (rtbvh::Node16: per child (lo, hi) pairs for x, y, z as binary16 of coordinate x boxScale, outward)
   const float s = boxScale;
-  const uint32_t h[12] = {half_directed(B0.lx * s, false), half_directed(B0.ly * s, false), half_directed(B0.lz * s, false),
-                          half_directed(B0.hx * s, true),  half_directed(B0.hy * s, true),  half_directed(B0.hz * s, true),
-                          half_directed(B1.lx * s, false), half_directed(B1.ly * s, false), half_directed(B1.lz * s, false),
-                          half_directed(B1.hx * s, true),  half_directed(B1.hy * s, true),  half_directed(B1.hz * s, true)};
+  const uint32_t h[12] = {half_directed(B0.lx * s, false), half_directed(B0.hx * s, true), half_directed(B0.ly * s, false),
+                          half_directed(B0.hy * s, true),  half_directed(B0.lz * s, false), half_directed(B0.hz * s, true),
+                          half_directed(B1.lx * s, false), half_directed(B1.hx * s, true), half_directed(B1.ly * s, false),
+                          half_directed(B1.hy * s, true),  half_directed(B1.lz * s, false), half_directed(B1.hz * s, true)};
   nodes16[2 * (size_t)i + 0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
   nodes16[2 * (size_t)i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, (uint32_t)child[0], (uint32_t)child[1]);
 }

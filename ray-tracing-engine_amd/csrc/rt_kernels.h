@@ -28,7 +28,7 @@ namespace rtk {
 
 // Device-resident flattened scene (all pointers are HBM allocations of rt_ctx).
 struct DevScene {
-  const uint4* nodes;      // n_nodes x 32 B: 12 x f16 box planes (lo0 hi0 lo1 hi1, scaled) + 2 child refs
+  const uint4* nodes;      // n_nodes x 32 B: 12 x f16 box planes ((lo, hi) per axis, child 0 then child 1, scaled) + 2 child refs
   const float4* tris;      // n_tris x 48 B, BVH leaf order: {p0,e1.x}{e1.yz,e2.xy}{e2.z,id,mesh,-}
   const float4* trisRef;   // same records in reference (mesh,tri) order (brute-force path)
   const uint4* triShade;   // per global triangle id: {v0,v1,v2 (global vertex ids), mesh}
