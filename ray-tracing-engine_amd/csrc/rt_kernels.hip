@@ -700,7 +700,7 @@ static_assert(VP_KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 
 template <bool STATS, int LT>
 RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
-                      f3 point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
+                      f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
                       uint32_t* over = nullptr) {
   const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
   float* fp = reinterpret_cast<float*>(pool);
@@ -726,8 +726,10 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       fp[VP_DIR + (3 * l + 0) * 64 + lane] = tl.x, fp[VP_DIR + (3 * l + 1) * 64 + lane] = tl.y, fp[VP_DIR + (3 * l + 2) * 64 + lane] = tl.z;
     }
     if (bounce) {
-      bdir = hemisphere_sample(g, hitNormal);
-      fp[VP_BDIR + lane] = bdir.x, fp[VP_BDIR + 64 + lane] = bdir.y, fp[VP_BDIR + 128 + lane] = bdir.z;
+      // (the caller's copy is read back from the pool after the loop: `point` and the bounce
+      // direction do not occupy registers while the wave traverses)
+      const f3 bd = hemisphere_sample(g, hitNormal);
+      fp[VP_BDIR + lane] = bd.x, fp[VP_BDIR + 64 + lane] = bd.y, fp[VP_BDIR + 128 + lane] = bd.z;
       keys[lane] = ~0ull;
     }
     listB[lanes_below(amask)] = (uint8_t)lane;
@@ -844,13 +846,18 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   }
   wave_sync();
   PH(PH_POOLMISC);
+  // `point` and the bounce direction come back from the pool (the same bits; lanes without a
+  // vertex read stale words nobody uses): nothing of them is live while the wave traverses
+  const f3 pt = mk(fp[VP_PT + lane], fp[VP_PT + 64 + lane], fp[VP_PT + 128 + lane]);
+  point = pt;
+  if (bounce) bdir = mk(fp[VP_BDIR + lane], fp[VP_BDIR + 64 + lane], fp[VP_BDIR + 128 + lane]);
   if (alive) {
     const BsdfBase base = bsdf_base(S.mats[mesh], hitNormal, -rayDir);  // the light-independent half, once
     for (uint32_t l = 0; l < nl; l++) {
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
       const f3 toLight = mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
       const f3 bsdf = bsdf_apply(base, toLight);
-      const f3 radiance = light_eval(S.lights[l], point);
+      const f3 radiance = light_eval(S.lights[l], pt);
       color = color + radiance * bsdf;
     }
     if (bounce) {
