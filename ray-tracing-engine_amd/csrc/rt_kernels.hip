@@ -75,7 +75,9 @@ RT_DEV float safe_inv(float d) {
   // reciprocal only feeds the (padded, conservative) slab test, never a reference
   // expression, so the 1-ulp hardware v_rcp_f32 is enough: its error is four orders
   // below the box padding in t units.
-  return fabsf(d) < 1e-20f ? copysignf(1e20f, d) : __builtin_amdgcn_rcpf(d);
+  // (clamped, not selected: rcp(+-0) and rcp(denormal) are +-inf, med3 brings them to +-1e20 —
+  // two instructions instead of compare + copysign + select)
+  return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d), -1e20f, 1e20f);
 }
 
 RT_DEV f3 f4xyz(const float4& a) { return mk(a.x, a.y, a.z); }
@@ -216,7 +218,8 @@ struct Trav {
     // with p ~ 3e-8).  The slab test, built from min/max that drop
     // NaNs, would instead accept every box: ONE such ray walks all 500k nodes of the
     // 1M-triangle scene (measured: +0.6 s on a 50 ms frame).  Same result, no walk:
-    if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) cur = TERM;
+    // (three two-operand unordered tests)
+    if (__builtin_isunordered(o.x, o.y) | __builtin_isunordered(o.z, d.x) | __builtin_isunordered(d.y, d.z)) cur = TERM;
   }
   RT_DEV bool live() const { return cur != TERM; }
 
@@ -826,22 +829,29 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       myK = newK, myJ = newJ;
     }
     if (__ballot(T.live()) == 0) break;
-    if (T.shared && T.live()) {
-      // several lanes may now serve this ray: stop at a decided any-hit
-      // ray, prune with the closest hit anyone has found so far
-      if (T.anyHit) {
-        if ((res[myK * 2 + (myJ >> 5)] >> (myJ & 31)) & 1u) T.cur = TERM;
-      } else {
-        T.refresh_best();
+    // Rounds until enough lanes are free for the next hand-out or steal (the same
+    // thresholds as above, so the schedule is the one a check per round gives — without
+    // walking through the bookkeeping in the rounds where it cannot do anything)
+    const int need = min(64, head < R ? (int)S.refillT : (int)S.stealT);
+    for (;;) {
+      if (T.shared && T.live()) {
+        // several lanes may now serve this ray: stop at a decided any-hit
+        // ray, prune with the closest hit anyone has found so far
+        if (T.anyHit) {
+          if ((res[myK * 2 + (myJ >> 5)] >> (myJ & 31)) & 1u) T.cur = TERM;
+        } else {
+          T.refresh_best();
+        }
       }
-    }
-    const bool was = T.live();
-    PH(PH_POOLMISC);
-    if (head >= R) PHC(PH_TAIL);
-    T.template round<STATS>(S, st);
-    if (was && !T.live() && T.found) {
-      if (myK < nl) atomicOr(&res[myK * 2 + (myJ >> 5)], 1u << (myJ & 31));
-      else if (!T.shared) T.publish();  // shared rays publish every improvement as it happens
+      const bool was = T.live();
+      PH(PH_POOLMISC);
+      if (head >= R) PHC(PH_TAIL);
+      T.template round<STATS>(S, st);
+      if (was && !T.live() && T.found) {
+        if (myK < nl) atomicOr(&res[myK * 2 + (myJ >> 5)], 1u << (myJ & 31));
+        else if (!T.shared) T.publish();  // shared rays publish every improvement as it happens
+      }
+      if (__popcll(__ballot(!T.live())) >= need) break;
     }
   }
   wave_sync();
