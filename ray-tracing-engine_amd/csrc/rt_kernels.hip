@@ -192,7 +192,11 @@ struct Trav {
   unsigned long long* sharedKey;
   uint32_t pj;
 
-  RT_DEV int depth() const { return (int)(top - base) / BLOCK + (SS ? ov : 0); }  // entries on the stack (live lanes only)
+  // entries on the stack (live lanes only: top >= base there, so the byte distance is unsigned —
+  // a signed 64-bit pointer difference and division cost seven instructions)
+  RT_DEV int depth() const {
+    return (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)base) / (4u * BLOCK)) + (SS ? ov : 0);
+  }
   RT_DEV void idle(uint32_t* stack, uint32_t* overflow = nullptr, uint32_t ssRows = 0) {
     cur = TERM, found = false, base = top = stack, stolen = 0, shared = false;
     over = overflow, limit = stack + ssRows * BLOCK, ov = 0;
@@ -785,21 +789,26 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       // victim's registers.
       uint16_t* list16 = reinterpret_cast<uint16_t*>(list);
       uint32_t given = 0;
+      // entries this lane could hand over (short stack: only those resident in LDS)
+      int avail = T.live() ? T.depth() - T.stolen : 0;
+      if (LT & LT_SS) avail = min(avail, (int)S.ssRows - T.stolen);
+      // (the passes only write the list; the lane's own state changes once, after them —
+      // per-lane flags updated inside a loop with exits cost a dozen mask instructions per pass)
+      int gave = 0;
       for (int pass = 0; pass < 4; pass++) {
-        // (short stack: only the entries resident in LDS can be handed over)
-        const bool canGive = T.live() && T.depth() > T.stolen && (!(LT & LT_SS) || T.stolen < (int)S.ssRows);
+        const bool canGive = avail > pass;
         const uint64_t vmask = __ballot(canGive);
         if (vmask == 0 || given >= (uint32_t)nIdle) break;
-        if (canGive) {
-          const uint32_t slot = given + lanes_below(vmask);
-          if (slot < (uint32_t)nIdle) {
-            list16[slot] = (uint16_t)(lane | ((uint32_t)T.stolen << 6));
-            T.stolen++;
-            if (!T.shared && !T.anyHit && T.found) T.publish();  // what it has found so far
-            T.shared = true;
-          }
-        }
+        const uint32_t slot = given + lanes_below(vmask);
+        const bool gives = canGive && slot < (uint32_t)nIdle;
+        if (gives) list16[slot] = (uint16_t)(lane | ((uint32_t)(T.stolen + pass) << 6));
+        gave += gives ? 1 : 0;
         given += (uint32_t)__popcll(vmask);
+      }
+      if (gave) {
+        if (!T.shared && !T.anyHit && T.found) T.publish();  // what it has found so far
+        T.shared = true;
+        T.stolen += gave;
       }
       if (given != 0) {
         given = given < (uint32_t)nIdle ? given : (uint32_t)nIdle;
