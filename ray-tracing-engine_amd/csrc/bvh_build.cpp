@@ -640,7 +640,9 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
           halfToFloat(q.box1[2 * a]) > n.lo1[a] * out.boxScale || halfToFloat(q.box1[2 * a + 1]) < n.hi1[a] * out.boxScale)
         throw std::runtime_error("internal error: packed box does not contain the float box");
     }
-    q.child[0] = n.child[0], q.child[1] = n.child[1];
+    // inner refs as BYTE offsets of the 32-B record (the traversal adds them to the base as they
+    // are); leaf codes (negative) unchanged
+    for (int c = 0; c < 2; ++c) q.child[c] = n.child[c] >= 0 ? n.child[c] * 32 : n.child[c];
   }
 }
 

@@ -294,7 +294,8 @@ __global__ void k_level_emit(const WorkItem* __restrict__ items, uint32_t count,
                           half_directed(B1.lx * s, false), half_directed(B1.hx * s, true), half_directed(B1.ly * s, false),
                           half_directed(B1.hy * s, true),  half_directed(B1.lz * s, false), half_directed(B1.hz * s, true)};
   nodes16[2 * (size_t)i + 0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
-  nodes16[2 * (size_t)i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, (uint32_t)child[0], (uint32_t)child[1]);
+  nodes16[2 * (size_t)i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, (uint32_t)(child[0] >= 0 ? child[0] * 32 : child[0]),
+                                          (uint32_t)(child[1] >= 0 ? child[1] * 32 : child[1]));  // (inner refs: byte offsets)
 }
 
 // 48-B triangle records (rtbvh::TriRec): p0, e1 = p1 - p0, e2 = p2 - p0 (the float subtraction

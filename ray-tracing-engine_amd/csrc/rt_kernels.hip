@@ -243,17 +243,18 @@ struct Trav {
       // 32-B packed node: 12 x f16 planes + 2 refs (32-bit byte offset from a uniform base:
       // the load takes the base from SGPRs)
       uint4 a, b;
-      if (LT == LT_ALL || (LT == LT_TOP && (uint32_t)cur < S.topK)) {
+      // (`cur` of an inner node is the byte offset of its record)
+      if (LT == LT_ALL || (LT == LT_TOP && (uint32_t)cur < S.topK * 32u)) {
         // from LDS (the tree copy starts at LDS byte offset 0 of the dynamic segment): a
         // divergent 32-B read costs the LDS a few cycles per wave where the vector L1 spends
         // one tag lookup per lane and dwordx4
-        uint32_t off = (uint32_t)cur << 5;
+        uint32_t off = (uint32_t)cur;
         if (LT == LT_TOP) asm volatile("" : "+v"(off));  // keep the two address spaces on separate paths (else: one flat load)
         lds_u4_ptr n = (lds_u4_ptr)(uintptr_t)(off + ldsNodeBase());
         const u32x4 va = n[0], vb = n[1];
         a = make_uint4(va.x, va.y, va.z, va.w), b = make_uint4(vb.x, vb.y, vb.z, vb.w);
       } else {
-        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + ((uint32_t)cur << 5));
+        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
         a = n[0], b = n[1];
       }
       PHC(PH_N_STEPS);
