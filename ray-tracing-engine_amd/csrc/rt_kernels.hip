@@ -238,8 +238,11 @@ struct Trav {
     // plain predicated region inside it: with the lane condition as the loop condition the
     // compiler keeps per-lane exit masks (20 scalar instructions + 4 branches per step, and a
     // wave issues one instruction of ANY kind per 4 cycles).
-    if (__ballot(cur >= 0)) for (;;) {
-     if (cur >= 0) {
+    // (the lanes of a step are the ballot the loop control has just counted: the mask goes
+    // straight back into exec — no second compare, no vector-to-scalar hand-over at the loop top)
+    uint64_t inner = __builtin_amdgcn_ballot_w64(cur >= 0);
+    if (inner) for (;;) {
+     if (__builtin_amdgcn_inverse_ballot_w64(inner)) {
       // 32-B packed node: 12 x f16 planes + 2 refs (32-bit byte offset from a uniform base:
       // the load takes the base from SGPRs)
       uint4 a, b;
@@ -299,7 +302,8 @@ struct Trav {
       // tail of a pool, with a handful of live rays, a round must not shrink to one step)
       // (desc < leafT and 3 * desc < live0, folded into one threshold)
      }
-      if (__popcll(__ballot(cur >= 0)) < exitBelow) break;
+      inner = __builtin_amdgcn_ballot_w64(cur >= 0);
+      if (__popcll(inner) < exitBelow) break;
     }
     PH(PH_DESCENT);
     if (cur < 0 && cur != TERM) {

@@ -30,9 +30,11 @@ for name, to in (("c2_kernel_stats.csv", "r02_c2_kernel_stats.csv"), ("c2_pmc_sp
                  ("c5_pmc_spp32.txt", "r02_c5_pmc_spp32.txt"), ("phase_C2.json", "r02_phase_C2.json"),
                  ("phase_C4.json", "r02_phase_C4.json"), ("phase_C5.json", "r02_phase_C5.json"), ("builders.txt", "r02_builders.txt"),
                  ("stream_vs_megakernel.json", "r02_stream_vs_megakernel.json"),
-                 ("bench_C2_under_rocprof.json", "r02_bench_C2_under_rocprof.json")):
+                 ("bench_C2_under_rocprof.json", "r02_bench_C2_under_rocprof.json"),
+                 ("c2_pmc_ta.txt", "r02_c2_pmc_ta.txt"), ("c5_pmc_ta.txt", "r02_c5_pmc_ta.txt"),
+                 ("c2_pmc_issue.txt", "r02_c2_pmc_issue.txt")):
     p = os.path.join(src, name)
-    if os.path.exists(p):
+    if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, to))
     else:
         print("missing", p)

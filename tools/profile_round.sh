@@ -19,8 +19,11 @@ grep '^{' $out/prof.log > $out/bench_C2_under_rocprof.json
 echo "kernel stats done"
 tools/pmc.sh c2 --spp 16 > /dev/null 2>&1; cp gpurun_out/pmc_c2/summary.txt $out/c2_pmc_spp16.txt
 tools/pmc.sh c5 --workload C5 --spp 32 > /dev/null 2>&1; cp gpurun_out/pmc_c5/summary.txt $out/c5_pmc_spp32.txt
+tools/pmc_ta.sh c2 --workload C2 --spp 16 > $out/c2_pmc_ta.txt 2>&1
+tools/pmc_ta.sh c5 --workload C5 --spp 32 > $out/c5_pmc_ta.txt 2>&1
+tools/pmc_issue.sh c2 --workload C2 --spp 16 > $out/c2_pmc_issue.txt 2>&1
 echo "pmc done"
-tools/phase_timing.sh C2 C4 C5 > $out/phase.log 2>&1; cp gpurun_out/phase_C2.json gpurun_out/phase_C4.json gpurun_out/phase_C5.json $out/
+tools/phase_timing.sh C2 C4 C5 > $out/phase.log 2>&1; for w in C2 C4 C5; do [ -s gpurun_out/phase_$w.json ] && cp gpurun_out/phase_$w.json $out/; done
 echo "phase done"
 python3 -m pytest tests/test_gpu_bvhbuild.py tests/test_gpu_kdbuild.py -m gpu -q -s -k "report or built_on_the_device" > $out/builders.txt 2>&1
 python3 tests/diag_stream_vs_fused.py lowres 640 2 > $out/stream_vs_megakernel.json 2> /dev/null
