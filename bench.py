@@ -214,7 +214,8 @@ def build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, rank, world):
     if nph:
         ctx.build_photon_map(nph, seed=1)  # emission + kd order on the device
     return pyrt.make_params(w, h, spp, mode=mode, seed=1, accel=accel, rank=rank, world=world, tile=32,
-                            use_photons=1 if nph else 0, k=k, photons_requested=nph, lanes_per_pixel=args.lpp)
+                            use_photons=1 if nph else 0, k=k, photons_requested=nph, lanes_per_pixel=args.lpp,
+                            wavefront=args.integrator == "wavefront")
 
 
 def main():
@@ -230,6 +231,8 @@ def main():
     ap.add_argument("--accel", default="bvh", choices=["bvh", "brute"])
     ap.add_argument("--leaf", type=int, default=0, help="BVH leaf size override (debug)")
     ap.add_argument("--lpp", type=int, default=0, help="samples of a pixel per wave override (debug)")
+    ap.add_argument("--integrator", default="fused", choices=["fused", "wavefront"],
+                    help="wavefront = the opt-in queue-based integrator (same image; DESIGN.md section 8)")
     args = ap.parse_args()
 
     if args.pmc_child:
@@ -382,7 +385,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s scene (%d triangles), %dx%d, -m %d -N %d, pixel RNG seed 1, %s"
-                                   % (args.workload, kind, scene.desc.n_triangles, w, h, mode, spp, args.accel),
+                                   % (args.workload, kind, scene.desc.n_triangles, w, h, mode, spp,
+                                      args.accel + (", wavefront integrator" if args.integrator == "wavefront" else "")),
                        "parallelism": "tiles32x%d, owned tiles gathered to rank 0" % world,
                        "rays_per_frame": rays_per_frame, "samples_per_frame": tot[4],
                        "knn_queries_per_frame": tot[5]},
