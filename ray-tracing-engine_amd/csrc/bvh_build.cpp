@@ -640,9 +640,16 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
           halfToFloat(q.box1[2 * a]) > n.lo1[a] * out.boxScale || halfToFloat(q.box1[2 * a + 1]) < n.hi1[a] * out.boxScale)
         throw std::runtime_error("internal error: packed box does not contain the float box");
     }
-    // inner refs as BYTE offsets of the 32-B record (the traversal adds them to the base as they
-    // are); leaf codes (negative) unchanged
-    for (int c = 0; c < 2; ++c) q.child[c] = n.child[c] >= 0 ? n.child[c] * 32 : n.child[c];
+    // inner refs as BYTE offsets of the 32-B record (the traversal adds them to the base as they are)
+    // — and so do leaves: ~(byte offset of the first 48-B record | count - 1) (the offset is a multiple of 16)
+    for (int c = 0; c < 2; ++c) {
+      if (n.child[c] >= 0) {
+        q.child[c] = n.child[c] * 32;
+      } else {
+        const uint32_t code = ~(uint32_t)n.child[c];
+        q.child[c] = (int32_t)~((code >> 3) * 48u | (code & 7u));
+      }
+    }
   }
 }
 

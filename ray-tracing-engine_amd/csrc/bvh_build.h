@@ -45,7 +45,8 @@ static_assert(sizeof(Node) == 64, "node record must be 64 bytes");
 // (rt_kernels.hip order_planes) instead of a min and a max per axis.
 struct alignas(16) Node16 {  // 32 B
   uint16_t box0[6], box1[6];  // box[2 * axis] = lo, box[2 * axis + 1] = hi
-  int32_t child[2];           // >= 0: BYTE offset of the child's record (index * 32); < 0: leaf code
+  int32_t child[2];           // >= 0: BYTE offset of the child's record (index * 32);
+                              // < 0: leaf, ~(byte offset of its first triangle record (first * 48) | count - 1)
 };
 static_assert(sizeof(Node16) == 32, "packed node record must be 32 bytes");
 

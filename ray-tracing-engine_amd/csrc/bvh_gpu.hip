@@ -155,6 +155,14 @@ __device__ __forceinline__ float half_area(const Box3& b) {
   return dx < 0.f ? 0.f : dx * dy + dy * dz + dz * dx;
 }
 
+// child ref of the packed record (rtbvh::Node16): inner = byte offset of the 32-B record; leaf =
+// ~(byte offset of its first 48-B triangle record | count - 1)
+__device__ inline uint32_t packed_ref(int32_t ref) {
+  if (ref >= 0) return (uint32_t)ref * 32u;
+  const uint32_t code = ~(uint32_t)ref;
+  return ~((code >> 3) * 48u | (code & 7u));
+}
+
 // float -> binary16 bits with directed rounding (bvh_build.cpp toHalfDirected, same bits)
 __device__ __forceinline__ uint32_t half_directed(float x, bool up) {
   const uint32_t u = __float_as_uint(x);
@@ -294,8 +302,7 @@ __global__ void k_level_emit(const WorkItem* __restrict__ items, uint32_t count,
                           half_directed(B1.lx * s, false), half_directed(B1.hx * s, true), half_directed(B1.ly * s, false),
                           half_directed(B1.hy * s, true),  half_directed(B1.lz * s, false), half_directed(B1.hz * s, true)};
   nodes16[2 * (size_t)i + 0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
-  nodes16[2 * (size_t)i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, (uint32_t)(child[0] >= 0 ? child[0] * 32 : child[0]),
-                                          (uint32_t)(child[1] >= 0 ? child[1] * 32 : child[1]));  // (inner refs: byte offsets)
+  nodes16[2 * (size_t)i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, packed_ref(child[0]), packed_ref(child[1]));
 }
 
 // 48-B triangle records (rtbvh::TriRec): p0, e1 = p1 - p0, e2 = p2 - p0 (the float subtraction

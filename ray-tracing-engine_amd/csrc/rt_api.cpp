@@ -389,8 +389,8 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     return fail(RT_ERR_INVALID, "scene descriptor has null arrays");
   if (sc->n_meshes == 0 || sc->n_vertices == 0 || sc->n_triangles == 0)
     return fail(RT_ERR_INVALID, "empty scene");
-  // (node refs are 31-bit byte offsets of 32-B records, leaf codes hold first << 3)
-  if (sc->n_triangles >= (1u << 26)) return fail(RT_ERR_UNSUPPORTED, "more than 2^26 - 1 triangles");
+  // (node and leaf refs are 31-bit byte offsets of 32-B node / 48-B triangle records)
+  if (sc->n_triangles >= (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "more than 2^25 - 1 triangles");
   int rc = select_device(opt ? opt->device : 0);
   if (rc != RT_OK) return rc;
 

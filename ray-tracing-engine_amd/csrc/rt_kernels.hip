@@ -308,17 +308,19 @@ struct Trav {
     PH(PH_DESCENT);
     if (cur < 0 && cur != TERM) {
       const uint32_t code = ~(uint32_t)cur;
-      const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+      // (byte offset of the leaf's first record | count - 1: the loads take the base from SGPRs)
+      const uint32_t cnt = (code & 7u) + 1u;
+      const char* const leaf = reinterpret_cast<const char*>(S.tris) + (code & ~7u);
       if (STATS) st.wleaf += (uint32_t)(__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63));
       // leaves hold 1..leaf_max (default 2) records: the first two are tested in
       // straight-line code with both records' loads in flight together
-      const float4* r = S.tris + 3 * (size_t)first;
+      const float4* r = reinterpret_cast<const float4*>(leaf);
       const uint32_t second = cnt > 1 ? 3u : 0u;  // a 1-triangle leaf re-reads its only record
       const float4 a0 = r[0], a1 = r[1], a2 = r[2];
       const float4 b0 = r[second + 0], b1 = r[second + 1], b2 = r[second + 2];
       bool stop = test_pair<STATS>(a0, a1, a2, b0, b1, b2, cnt > 1, st);
       for (uint32_t i = 2; i < cnt && !stop; i++) {
-        const float4* q = S.tris + 3 * (size_t)(first + i);
+        const float4* q = reinterpret_cast<const float4*>(leaf + 48u * i);
         stop = test_record<STATS>(q[0], q[1], q[2], st);
       }
       cur = stop ? TERM : (int32_t)peek();
