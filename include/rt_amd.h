@@ -154,6 +154,8 @@ typedef struct rt_ctx rt_ctx;
 int rt_abi_version(void);
 const char* rt_last_error(void);
 
+/* Uploads the scene and builds its BVH.  RT_ERR_INVALID: null arrays / empty scene;
+ * RT_ERR_UNSUPPORTED: 2^25 triangles or more (node and leaf refs are 31-bit byte offsets). */
 int rt_create(const rt_scene_desc* scene, const rt_options* opt, rt_ctx** out);
 void rt_destroy(rt_ctx* ctx);
 
