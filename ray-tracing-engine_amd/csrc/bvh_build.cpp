@@ -114,22 +114,27 @@ struct Builder {
       return b + bestPos;
     }
 
-    constexpr int NB = 16;
+    constexpr int NBMAX = 128;
+    static const int nbEnv = getenv("RT_BVH_BINS") ? atoi(getenv("RT_BVH_BINS")) : 0;
+    // 64 bins per axis (RT_BVH_BINS overrides).  Measured, Mrays/s and node visits per ray: 1 M-triangle
+    // lattice 16 bins 6,620 / 38.8, 64 bins 6,781 / 37.5; 8 M triangles 4,037 / 48.1 -> 4,633 / 42.5
+    // (16 bins across an 88-cell lattice cut through the cells; 32, 64 and 128 are within 2 % of each other)
+    const int NB = nbEnv >= 2 && nbEnv <= NBMAX ? nbEnv : 64;
     float bestCost = std::numeric_limits<float>::infinity();
     int bestAxis = -1, bestBin = -1;
     for (int ax = 0; ax < 3; ++ax) {
       const float ext = cb.hi[ax] - cb.lo[ax];
       if (!(ext > 0.f)) continue;
-      Box bb[NB];
-      uint32_t cnt[NB] = {0};
+      Box bb[NBMAX];
+      uint32_t cnt[NBMAX] = {0};
       for (int k = 0; k < NB; ++k) bb[k].reset();
       const float scale = NB / ext;
       for (uint32_t i = b; i < e; ++i) {
         int k = std::min(NB - 1, std::max(0, static_cast<int>((prims[i].c[ax] - cb.lo[ax]) * scale)));
         bb[k].grow(prims[i].box), ++cnt[k];
       }
-      float rightArea[NB];
-      uint32_t rightCnt[NB];
+      float rightArea[NBMAX];
+      uint32_t rightCnt[NBMAX];
       Box acc;
       acc.reset();
       uint32_t c = 0;
@@ -483,7 +488,37 @@ static void relayoutTop(std::vector<Node>& nodes, uint32_t kTop) {
   // way; T <= 1 is plain pre-order.  (Measured on the 1 M-triangle scene: see DESIGN.md.)
   std::sort(heap.begin(), heap.end(), [](const Item& x, const Item& y) { return y < x; });
   static const int treelet = getenv("RT_BVH_TREELET") ? atoi(getenv("RT_BVH_TREELET")) : 0;
+  // RT_BVH_LAYOUT (experiment): 1 = depth-first over SIBLING PAIRS (the two children of a node
+  // get consecutive indices — one 64-B block —, then the pairs below child 0, then those below
+  // child 1); 2 = breadth-first below the top.
+  static const int layout = getenv("RT_BVH_LAYOUT") ? atoi(getenv("RT_BVH_LAYOUT")) : 0;
   std::vector<int32_t> st;
+  if (layout == 1) {
+    for (const Item& r : heap) newOf[r.idx] = static_cast<int32_t>(next++);  // the roots below the top, largest first
+    for (const Item& r : heap) {
+      st.push_back(r.idx);
+      while (!st.empty()) {
+        const int32_t x = st.back();
+        st.pop_back();
+        const int32_t c0 = nodes[x].child[0], c1 = nodes[x].child[1];
+        if (c0 >= 0) newOf[c0] = static_cast<int32_t>(next++);
+        if (c1 >= 0) newOf[c1] = static_cast<int32_t>(next++);
+        if (c1 >= 0) st.push_back(c1);
+        if (c0 >= 0) st.push_back(c0);
+      }
+    }
+    heap.clear();
+  } else if (layout == 2) {
+    std::vector<int32_t> q;
+    for (const Item& r : heap) q.push_back(r.idx);
+    for (size_t h = 0; h < q.size(); ++h) {
+      const int32_t x = q[h];
+      newOf[x] = static_cast<int32_t>(next++);
+      if (nodes[x].child[0] >= 0) q.push_back(nodes[x].child[0]);
+      if (nodes[x].child[1] >= 0) q.push_back(nodes[x].child[1]);
+    }
+    heap.clear();
+  }
   for (const Item& r : heap) {
     st.push_back(r.idx);
     while (!st.empty()) {
