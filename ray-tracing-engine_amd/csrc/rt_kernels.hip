@@ -118,6 +118,10 @@ RT_DEV bool slab_ordered(float nx, float fx, float ny, float fy, float nz, float
 // (lo, hi) f16 pair -> (near, far): rotate by 16 when the ray runs against the axis
 RT_DEV uint32_t order_planes(uint32_t w, uint32_t rot) { return __builtin_amdgcn_alignbit(w, w, rot); }
 
+// lane mask of a predicate (HIP's __ballot(int) goes through a 0/1 register and a compare where
+// the compiler does not fold it: two vector instructions per use)
+RT_DEV uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 constexpr int32_t TERM = (int32_t)0x80000000;  // "this lane holds no live ray"
 
 // Every LDS exchange in this file is between lanes of ONE wave (a wave owns its stack,
@@ -229,10 +233,10 @@ struct Trav {
 
   template <bool STATS>
   RT_DEV void round(const DevScene& S, LaneStats& st) {
-    const int live0 = __popcll(__ballot(cur != TERM));
+    const int live0 = __popcll(wave_ballot(cur != TERM));
     const int exitBelow = min((int)S.leafT, (live0 + 2) / 3);
     uint32_t statWait = 0, statIdle = 0;
-    if (STATS) statWait = (uint32_t)__popcll(__ballot(cur < 0 && cur != TERM)), statIdle = (uint32_t)__popcll(__ballot(cur == TERM));
+    if (STATS) statWait = (uint32_t)__popcll(wave_ballot(cur < 0 && cur != TERM)), statIdle = (uint32_t)__popcll(wave_ballot(cur == TERM));
     PHC(PH_N_ROUNDS);
     // The loop is WAVE-UNIFORM (a ballot decides, every lane leaves together) and the step a
     // plain predicated region inside it: with the lane condition as the loop condition the
@@ -267,7 +271,7 @@ struct Trav {
       const int2 ch = make_int2((int)b.z, (int)b.w);
       if (STATS) {
         st.nodes++;
-        if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63)) st.wnode++, st.lwait += statWait, st.lidle += statIdle;
+        if (__ffsll((long long)wave_ballot(true)) - 1 == (int)(threadIdx.x & 63)) st.wnode++, st.lwait += statWait, st.lidle += statIdle;
       }
       float t0, t1;
       const uint32_t x0 = order_planes(a.x, rotX), y0 = order_planes(a.y, rotY), z0 = order_planes(a.z, rotZ);
@@ -311,7 +315,7 @@ struct Trav {
       // (byte offset of the leaf's first record | count - 1: the loads take the base from SGPRs)
       const uint32_t cnt = (code & 7u) + 1u;
       const char* const leaf = reinterpret_cast<const char*>(S.tris) + (code & ~7u);
-      if (STATS) st.wleaf += (uint32_t)(__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63));
+      if (STATS) st.wleaf += (uint32_t)(__ffsll((long long)wave_ballot(true)) - 1 == (int)(threadIdx.x & 63));
       // leaves hold 1..leaf_max (default 2) records: the first two are tested in
       // straight-line code with both records' loads in flight together
       const float4* r = reinterpret_cast<const float4*>(leaf);
@@ -407,7 +411,7 @@ RT_DEV bool traverse(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, Hi
   T.idle(stack, over, S.ssRows);
   if (on) T.start(o, d, S.invBoxScale);
   PH(PH_SETUP);
-  while (__ballot(T.live()) != 0) {
+  while (wave_ballot(T.live()) != 0) {
     T.template round<STATS>(S, st);
     PH(PH_PRIMARY);  // (round() itself books descent and leaf time; the primary cast is coherent)
   }
@@ -724,7 +728,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   uint8_t* listB = reinterpret_cast<uint8_t*>(list);
   uint32_t* res = pool + VP_RES;
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(pool + VP_KEY);
-  const uint64_t amask = __ballot(alive);
+  const uint64_t amask = wave_ballot(alive);
   const uint32_t n = (uint32_t)__popcll(amask);
   f3 color = mk(0.f, 0.f, 0.f);
   nextFound = false;
@@ -760,7 +764,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   T.sharedKey = keys, T.pj = 0;
   uint32_t* stackBase = stack - lane;
   for (;;) {
-    const uint64_t idle = __ballot(!T.live());
+    const uint64_t idle = wave_ballot(!T.live());
     const int nIdle = __popcll(idle);
     // a lane may be given a ray (hand-out) or a subtree of one (stealing); the ray is
     // started in ONE place below, so that the traversal state has a single definition
@@ -804,7 +808,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       int gave = 0;
       for (int pass = 0; pass < 4; pass++) {
         const bool canGive = avail > pass;
-        const uint64_t vmask = __ballot(canGive);
+        const uint64_t vmask = wave_ballot(canGive);
         if (vmask == 0 || given >= (uint32_t)nIdle) break;
         const uint32_t slot = given + lanes_below(vmask);
         const bool gives = canGive && slot < (uint32_t)nIdle;
@@ -844,7 +848,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       T.anyHit = newK < nl, T.pj = newJ, T.shared = newShared;
       myK = newK, myJ = newJ;
     }
-    if (__ballot(T.live()) == 0) break;
+    if (wave_ballot(T.live()) == 0) break;
     // Rounds until enough lanes are free for the next hand-out or steal (the same
     // thresholds as above, so the schedule is the one a check per round gives — without
     // walking through the bookkeeping in the rounds where it cannot do anything)
@@ -867,7 +871,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
         if (myK < nl) atomicOr(&res[myK * 2 + (myJ >> 5)], 1u << (myJ & 31));
         else if (!T.shared) T.publish();  // shared rays publish every improvement as it happens
       }
-      if (__popcll(__ballot(!T.live())) >= need) break;
+      if (__popcll(wave_ballot(!T.live())) >= need) break;
     }
   }
   wave_sync();
@@ -975,7 +979,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
       const bool hit0 = cast<false, false, STATS, LT>(S, alive, o, d, L.stack, h, st, L.over);
       if (alive && !hit0) primary = false, alive = false;
       for (int depth = 0; depth < nvert; depth++) {
-        if (__ballot(alive) == 0) break;
+        if (wave_ballot(alive) == 0) break;
         const bool bounce = A.mode == RT_MODE_PATH && depth + 1 < nvert;  // wave-uniform
         f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, bdir = nrm;
         uint32_t mesh = 0;
@@ -1003,7 +1007,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
         if (depth == 0) primary = false;
         alive = false;
       }
-      if (__ballot(alive) == 0) break;
+      if (wave_ballot(alive) == 0) break;
       f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, c = nrm;
       if (alive) vertex_setup(S, h, nrm, pt);
       if (PHOTON) {
@@ -1160,7 +1164,7 @@ __global__ __launch_bounds__(1024, 8) void k_trace_stream(DevScene S, const floa
   float4 so = make_float4(0.f, 0.f, 0.f, 0.f), sd = so;
   bool more = true;  // rays left to stage
   for (;;) {
-    const uint64_t idle = __ballot(!T.live());
+    const uint64_t idle = wave_ballot(!T.live());
     const int nIdle = __popcll(idle);
     if ((nIdle >= (int)S.refillT || nIdle == 64) && (sHead < sCount || more)) {
       if (sHead < sCount) {
@@ -1193,7 +1197,7 @@ __global__ __launch_bounds__(1024, 8) void k_trace_stream(DevScene S, const floa
         }
       }
     }
-    if (__ballot(T.live()) == 0) {
+    if (wave_ballot(T.live()) == 0) {
       if (!more) break;
       continue;
     }
