@@ -997,6 +997,9 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
         const bool bounce = A.mode == RT_MODE_PATH && depth + 1 < nvert;  // wave-uniform
         f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, bdir = nrm;
         uint32_t mesh = 0;
+        // (the vertex set-up is three dependent loads deep: it goes out ahead of other waves'
+        // arithmetic, like the pool loop that follows; +0.4 % on C2)
+        if (!(LT & LT_NOPRIO)) __builtin_amdgcn_s_setprio(1);
         if (alive) vertex_setup_ray(S, h.id, o, d, nrm, pt, mesh);
         // (Renderer.cpp:164: the hemisphere sample is drawn after every shaded vertex;
         // after the LAST one the reference draws it too but never traces it, and the
