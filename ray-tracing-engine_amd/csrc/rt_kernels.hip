@@ -291,8 +291,13 @@ struct Trav {
       // select-based step: one divergent branch (the pop) instead of a four-way chain;
       // the far child is stored unconditionally (the slot is simply not claimed unless
       // both children were hit)
-      const bool both = h0 && h1, any = h0 || h1;
-      const bool takeY = h1 & (!h0 | (t1 < t0));  // which child to enter (lane-mask logic: no selects, no branch)
+      // which child to enter: child 1 unless child 0 is hit and not farther.  Lane masks by hand
+      // (ballots and scalar bit operations: three compares, and / and-not / or / and) — left to
+      // the compiler the negation becomes a fourth compare.
+      const uint64_t m0 = __builtin_amdgcn_ballot_w64(h0), m1 = __builtin_amdgcn_ballot_w64(h1);
+      const uint64_t mle = __builtin_amdgcn_ballot_w64(t0 <= t1);
+      const bool takeY = __builtin_amdgcn_inverse_ballot_w64(m1 & ~(m0 & mle));
+      const bool both = __builtin_amdgcn_inverse_ballot_w64(m0 & m1), any = __builtin_amdgcn_inverse_ballot_w64(m0 | m1);
       if (SS) {
         const bool full = top == limit;  // the LDS rows are used up: this entry goes to HBM
         const uint32_t far = (uint32_t)(takeY ? ch.x : ch.y);
