@@ -267,7 +267,13 @@ struct Trav {
         // one tag lookup per lane and dwordx4
         uint32_t off = (uint32_t)cur;
         if (LT == LT_TOP) asm volatile("" : "+v"(off));  // keep the two address spaces on separate paths (else: one flat load)
+#ifdef RT_PHASE_TIMING
         lds_u4_ptr n = (lds_u4_ptr)(uintptr_t)(off + ldsNodeBase());
+#else
+        // (no static LDS in the product build: the dynamic segment, i.e. the tree copy, starts at LDS
+        // address 0 — checked once on the host, launch_render2 — so a node's offset IS its address)
+        lds_u4_ptr n = (lds_u4_ptr)(uintptr_t)off;
+#endif
         const u32x4 va = n[0], vb = n[1];
         a = make_uint4(va.x, va.y, va.z, va.w), b = make_uint4(vb.x, vb.y, vb.z, vb.w);
       } else {
@@ -1463,14 +1469,21 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
 // Dynamic LDS beyond 64 KiB must be allowed per kernel AND per device (one process may drive
 // several devices: rt_group): `done` is the caller's per-kernel bit mask of devices already set.
 template <class K>
-static void allow_big_lds(K kernel, unsigned long long& done) {
+static bool allow_big_lds(K kernel, unsigned long long& done) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
-  if (done & (1ull << dev)) return;
+  if (done & (1ull << dev)) return true;
+#ifndef RT_PHASE_TIMING
+  // Trav::round takes a node's byte offset as its LDS address: the tree copy must start at LDS
+  // address 0, i.e. the kernel must not have static LDS in front of the dynamic segment
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) != hipSuccess || fa.sharedSizeBytes != 0) return false;
+#endif
   // (256 B short of the CU's 160 KiB: plan_persist leaves that room for the diagnostic build's
   // static LDS, and the attribute is refused when static + dynamic exceed the CU)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
   done |= 1ull << dev;
+  return true;
 }
 
 // LDS plan of the persistent pooled kernel: W waves per workgroup (one workgroup per CU),
@@ -1540,7 +1553,7 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
 #define RT_LAUNCH_PERSIST(ST, LTV)                                                                                      \
   do {                                                                                                                  \
     static unsigned long long done = 0;                                                                                 \
-    allow_big_lds(&k_render_persist<ST, LTV>, done);                                                                    \
+    if (!allow_big_lds(&k_render_persist<ST, LTV>, done)) return hipErrorInvalidConfiguration;                          \
     hipLaunchKernelGGL((k_render_persist<ST, LTV>), dim3(wgs), dim3(64u * P.waves), P.ldsBytes, stream, S2, A2, accum,  \
                        counters);                                                                                       \
   } while (0)
@@ -1618,11 +1631,11 @@ hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const floa
   wgs = wgs < perCU * numCUs ? wgs : perCU * numCUs;
   if (S2.topK >= S.n_nodes && S2.topK) {
     static unsigned long long done = 0;
-    allow_big_lds(&k_trace_stream<LT_ALL>, done);
+    if (!allow_big_lds(&k_trace_stream<LT_ALL>, done)) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL((k_trace_stream<LT_ALL>), dim3(wgs), dim3(64u * wpw), ldsBytes, stream, S2, rayO, rayD, n, res, counter, stackLevels);
   } else {
     static unsigned long long done = 0;
-    allow_big_lds(&k_trace_stream<LT_NONE>, done);
+    if (!allow_big_lds(&k_trace_stream<LT_NONE>, done)) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL((k_trace_stream<LT_NONE>), dim3(wgs), dim3(64u * wpw), ldsBytes, stream, S2, rayO, rayD, n, res, counter, stackLevels);
   }
   return hipGetLastError();
