@@ -116,10 +116,14 @@ struct Builder {
 
     constexpr int NBMAX = 128;
     static const int nbEnv = getenv("RT_BVH_BINS") ? atoi(getenv("RT_BVH_BINS")) : 0;
-    // 64 bins per axis (RT_BVH_BINS overrides).  Measured, Mrays/s and node visits per ray: 1 M-triangle
-    // lattice 16 bins 6,620 / 38.8, 64 bins 6,781 / 37.5; 8 M triangles 4,037 / 48.1 -> 4,633 / 42.5
-    // (16 bins across an 88-cell lattice cut through the cells; 32, 64 and 128 are within 2 % of each other)
-    const int NB = nbEnv >= 2 && nbEnv <= NBMAX ? nbEnv : 64;
+    // 64 bins per axis for ranges of 65,536 primitives and more, 16 below (RT_BVH_BINS / RT_BVH_BINS_FROM
+    // override).  Measured, Mrays/s and node visits per ray: 1 M-triangle lattice 16 bins 6,620 / 38.8,
+    // 64 bins 6,781 / 37.5; 8 M triangles 4,037 / 48.1 -> 4,633 / 42.5 (16 bins across an 88-cell lattice cut
+    // through the cells; 32, 64 and 128 are within 2 % of each other).  On the 11.7 k-triangle mesh the two
+    // binned top levels came out 5 % WORSE in node visits with 64 bins (greedy SAH is not monotone in the
+    // candidate set), and the big scenes keep their gain when only the large ranges get the fine bins.
+    static const int nbSplit = getenv("RT_BVH_BINS_FROM") ? atoi(getenv("RT_BVH_BINS_FROM")) : 65536;
+    const int NB = (int)n < nbSplit ? 16 : nbEnv >= 2 && nbEnv <= NBMAX ? nbEnv : 64;
     float bestCost = std::numeric_limits<float>::infinity();
     int bestAxis = -1, bestBin = -1;
     for (int ax = 0; ax < 3; ++ax) {
