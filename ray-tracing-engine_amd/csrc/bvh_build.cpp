@@ -439,7 +439,7 @@ ScenePlan planScene(const rt_scene_desc& sc, uint32_t leafMax) {
   int levels = 0;
   for (uint32_t n = sc.n_triangles; n > leafMax; n = (n + 1) / 2) ++levels;
   const char* slack = getenv("RT_BVH_SLACK");
-  P.depthCap = std::min(kMaxDepth - 1, levels + (slack ? atoi(slack) : (levels >= 19 ? 2 : 3)));
+  P.depthCap = std::min(kMaxDepth - 1, levels + (slack ? atoi(slack) : defaultDepthSlack(levels)));
   float padRef = std::max(1.f, P.maxAbs);
   for (int a = 0; a < 3; ++a)
     if (std::isfinite(sc.camera.position[a])) padRef = std::max(padRef, std::fabs(sc.camera.position[a]));
@@ -577,10 +577,8 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   // is what limits occupancy on big scenes; 3 spare levels keep SAH within 1 % of the
   // unconstrained tree (stress scene: depth 25 -> 22, cost 2203 -> 2221; 2 spare: 2562).
   const char* slack = getenv("RT_BVH_SLACK");
-  // balanced depth + 3; + 2 for scenes whose trees are 20+ levels deep anyway: one level is
-  // 256 B of LDS per wave, and at 21 levels (+ the sentinel row) 16 waves with their ray pools
-  // still fit a CU's 160 KiB, at 22 only 15 do (1 M triangles: -3 % rays/s; SAH cost +0.4 %)
-  const int defSlack = B.levelsFor(sc.n_triangles) >= 19 ? 2 : 3;
+  // (bvh_build.h defaultDepthSlack: 3; deep trees 2 plus the levels that do not cost a wave)
+  const int defSlack = defaultDepthSlack(B.levelsFor(sc.n_triangles));
   B.depthCap = std::min(kMaxDepth - 1, B.levelsFor(sc.n_triangles) + (slack ? atoi(slack) : defSlack));
   B.prims.resize(sc.n_triangles);
   out.trisRef.resize(sc.n_triangles);

@@ -59,6 +59,25 @@ struct alignas(16) TriRec { // 48 B
 static_assert(sizeof(TriRec) == 48, "triangle record must be 48 bytes");
 
 constexpr int kMaxDepth = 32;      // traversal stack entries per lane
+// LDS budget of the pooled render kernel (rt_kernels.hip plan_persist), which the depth cap is chosen
+// against: words per CU available to the waves, words of a wave's ray pool, words per stack row
+constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - 64u, kWavePoolWords = 1128u, kStackRowWords = 64u;
+// waves (of at most 16) that fit a CU beside their stacks for a tree of this depth (+1: the sentinel row)
+constexpr uint32_t wavesForDepth(int depth) {
+  const uint32_t w = kLdsWordsPerCU / ((uint32_t)(depth + 1) * kStackRowWords + kWavePoolWords);
+  return w < 16u ? w : 16u;
+}
+// Spare levels over the balanced depth.  3 keep SAH within 1 % of the unconstrained tree; trees of 19+
+// balanced levels get 2 — one level is 256 B of LDS per wave, and the 1 M-triangle scene keeps 16 waves at
+// 21 levels but only 15 at 22 (-3 % rays/s for +0.4 % SAH) — plus every further level (up to 5) that does
+// not cost another wave: the 8 M-triangle scene has 14 waves from 24 to 27 levels, and 27 instead of 24
+// is worth 15 % there (node visits per ray 42.5 -> 40.1).
+constexpr int defaultDepthSlack(int levels) {
+  if (levels < 19) return 3;
+  int s = 2;
+  while (s < 5 && levels + s + 1 < kMaxDepth && wavesForDepth(levels + s + 1) == wavesForDepth(levels + 2)) ++s;
+  return s;
+}
 constexpr uint32_t kTopNodes = 4096;  // nodes [0, kTopNodes) are the most-visited top of the tree (LDS candidates)
 
 inline int32_t encodeLeaf(uint32_t first, uint32_t count) { return ~static_cast<int32_t>((first << 3) | (count - 1)); }

@@ -738,6 +738,7 @@ constexpr int VP_PT = 0, VP_DIR = 192, VP_BDIR = VP_DIR + 192 * POOL_L, VP_KEY =
               VP_RES = VP_LIST + 32;
 constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
 static_assert(VP_KEY % 2 == 0, "64-bit keys need 8-byte alignment");
+static_assert(VP_WORDS == (int)rtbvh::kWavePoolWords && BLOCK == (int)rtbvh::kStackRowWords, "bvh_build.h sizes the depth cap with these");
 
 template <bool STATS, int LT>
 RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
@@ -1493,7 +1494,7 @@ struct PersistPlan {
   uint32_t ssRows;  // > 0: short stack (that many entries in LDS, the rest in HBM)
 };
 static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
-  const uint32_t total = 160u * 1024u / 4u - 64u;  // words (a little room for the diagnostic build's statics)
+  const uint32_t total = rtbvh::kLdsWordsPerCU;  // words (a little room for the diagnostic build's statics)
   const uint32_t waveWords = A.stackLevels * BLOCK + VP_WORDS;
   static const int wEnv = getenv("RT_PERSIST_WAVES") ? atoi(getenv("RT_PERSIST_WAVES")) : 0;
   static const int kEnv = getenv("RT_TOPK") ? atoi(getenv("RT_TOPK")) : -1;
