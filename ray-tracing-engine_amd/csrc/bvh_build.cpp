@@ -439,7 +439,8 @@ ScenePlan planScene(const rt_scene_desc& sc, uint32_t leafMax) {
   int levels = 0;
   for (uint32_t n = sc.n_triangles; n > leafMax; n = (n + 1) / 2) ++levels;
   const char* slack = getenv("RT_BVH_SLACK");
-  P.depthCap = std::min(kMaxDepth - 1, levels + (slack ? atoi(slack) : defaultDepthSlack(levels)));
+  // (the plan is what the DEVICE builder works from; the host builder sets its own cap in build())
+  P.depthCap = std::min(kMaxDepth - 1, levels + (slack ? atoi(slack) : defaultDepthSlack(levels, false)));
   float padRef = std::max(1.f, P.maxAbs);
   for (int a = 0; a < 3; ++a)
     if (std::isfinite(sc.camera.position[a])) padRef = std::max(padRef, std::fabs(sc.camera.position[a]));

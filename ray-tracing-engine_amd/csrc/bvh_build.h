@@ -67,15 +67,21 @@ constexpr uint32_t wavesForDepth(int depth) {
   const uint32_t w = kLdsWordsPerCU / ((uint32_t)(depth + 1) * kStackRowWords + kWavePoolWords);
   return w < 16u ? w : 16u;
 }
-// Spare levels over the balanced depth.  3 keep SAH within 1 % of the unconstrained tree; trees of 19+
-// balanced levels get 2 — one level is 256 B of LDS per wave, and the 1 M-triangle scene keeps 16 waves at
-// 21 levels but only 15 at 22 (-3 % rays/s for +0.4 % SAH) — plus every further level (up to 5) that does
-// not cost another wave: the 8 M-triangle scene has 14 waves from 24 to 27 levels, and 27 instead of 24
-// is worth 15 % there (node visits per ray 42.5 -> 40.1).
-constexpr int defaultDepthSlack(int levels) {
+// Spare levels over the balanced depth.  3 keep SAH within 1 % of the unconstrained tree on small scenes.
+// From 19 balanced levels up a level costs waves (256 B of LDS per wave and level), and the trade was
+// measured on the lattice scenes: 1 M triangles (19 levels) +2 / +3 / +4 / +5 spare levels = 16 / 15 / 15 /
+// 14 waves = 402 / 415 / 416 / 393 ms with 37.5 / 36.7 / 36.7 / 35.0 node visits per ray; 8 M triangles
+// (22 levels) +2 ... +5 all 14 waves = 73.3 / 71.7 / 71.8 / 63.9 ms, +6 (13 waves) 68.6 ms.  So: up to 5
+// spare levels as long as 14 waves (or as many as +2 levels leave) still fit.
+// `sweepBuilder` = the host builder.  The device builder's Morton-cell splits gain nothing from a deeper cap
+// (1 M triangles: 433 ms at 21 levels / 16 waves, 466 ms at 24 / 14), so it only takes the spare levels
+// that cost no wave at all.
+constexpr int defaultDepthSlack(int levels, bool sweepBuilder = true) {
   if (levels < 19) return 3;
+  const uint32_t keep = wavesForDepth(levels + 2);
+  const uint32_t floorWaves = !sweepBuilder ? keep : keep < 14u ? keep : 14u;
   int s = 2;
-  while (s < 5 && levels + s + 1 < kMaxDepth && wavesForDepth(levels + s + 1) == wavesForDepth(levels + 2)) ++s;
+  while (s < 5 && levels + s + 1 < kMaxDepth && wavesForDepth(levels + s + 1) >= floorWaves) ++s;
   return s;
 }
 constexpr uint32_t kTopNodes = 4096;  // nodes [0, kTopNodes) are the most-visited top of the tree (LDS candidates)

@@ -109,4 +109,5 @@ def test_host_bvh_build_does_not_depend_on_thread_count():
     # a range large enough to fork several levels deep
     s = pyrt.Scene("stress", 32, 32)
     a, b = pyrt.bvh_build_host(s, 0, 1), pyrt.bvh_build_host(s, 0, 8)
-    assert a[1] == b[1] and a[0].n_nodes == b[0].n_nodes and a[0].max_depth == b[0].max_depth == 21
+    # (19 balanced levels + 5 spare: the deepest tree that still leaves 14 waves of LDS, bvh_build.h)
+    assert a[1] == b[1] and a[0].n_nodes == b[0].n_nodes and a[0].max_depth == b[0].max_depth == 24
