@@ -61,7 +61,13 @@ static_assert(sizeof(TriRec) == 48, "triangle record must be 48 bytes");
 constexpr int kMaxDepth = 32;      // traversal stack entries per lane
 // LDS budget of the pooled render kernel (rt_kernels.hip plan_persist), which the depth cap is chosen
 // against: words per CU available to the waves, words of a wave's ray pool, words per stack row
-constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - 64u, kWavePoolWords = 1128u, kStackRowWords = 64u;
+// (the diagnostic RT_PHASE_TIMING build keeps 256 B of static LDS; the product build has none)
+#ifdef RT_PHASE_TIMING
+constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - 64u;
+#else
+constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u;
+#endif
+constexpr uint32_t kWavePoolWords = 1128u, kStackRowWords = 64u;
 // waves (of at most 16) that fit a CU beside their stacks for a tree of this depth (+1: the sentinel row)
 constexpr uint32_t wavesForDepth(int depth) {
   const uint32_t w = kLdsWordsPerCU / ((uint32_t)(depth + 1) * kStackRowWords + kWavePoolWords);

@@ -1480,9 +1480,9 @@ static bool allow_big_lds(K kernel, unsigned long long& done) {
   hipFuncAttributes fa;
   if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) != hipSuccess || fa.sharedSizeBytes != 0) return false;
 #endif
-  // (256 B short of the CU's 160 KiB: plan_persist leaves that room for the diagnostic build's
-  // static LDS, and the attribute is refused when static + dynamic exceed the CU)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+  // (the diagnostic build stays 256 B short of the CU's 160 KiB for its static LDS: the attribute
+  // is refused when static + dynamic exceed the CU)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * rtbvh::kLdsWordsPerCU);
   done |= 1ull << dev;
   return true;
 }
@@ -1494,7 +1494,7 @@ struct PersistPlan {
   uint32_t ssRows;  // > 0: short stack (that many entries in LDS, the rest in HBM)
 };
 static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
-  const uint32_t total = rtbvh::kLdsWordsPerCU;  // words (a little room for the diagnostic build's statics)
+  const uint32_t total = rtbvh::kLdsWordsPerCU;  // words
   const uint32_t waveWords = A.stackLevels * BLOCK + VP_WORDS;
   static const int wEnv = getenv("RT_PERSIST_WAVES") ? atoi(getenv("RT_PERSIST_WAVES")) : 0;
   static const int kEnv = getenv("RT_TOPK") ? atoi(getenv("RT_TOPK")) : -1;
