@@ -1500,9 +1500,9 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   static const int kEnv = getenv("RT_TOPK") ? atoi(getenv("RT_TOPK")) : -1;
   const uint32_t cap = S.n_nodes < rtbvh::kTopNodes ? S.n_nodes : rtbvh::kTopNodes;
   // Measured (MI355X, Grays/s): occupancy comes first — 12 instead of 16 waves costs 15-17 %
-  // on every scene — and a PARTIAL top (LT_TOP: a branch per node step) gave C4 -2 %, while
-  // the whole tree in LDS (LT_ALL, no branch) gives C2 +5.6 %.  So: 16 waves; the tree goes
-  // to LDS only if all of it fits beside them.  RT_PERSIST_WAVES / RT_TOPK override.
+  // on every scene; the whole tree in LDS (LT_ALL, no branch) gives C2 +5.6 %.  So: as many
+  // waves as fit (at most 16), then as much of the tree as fits beside them.
+  // RT_PERSIST_WAVES / RT_TOPK override.
   PersistPlan best{0, 0, waveWords, 0, 0};
   // SHORT STACK (RT_SS=1; opt-in): 12 entries per lane in LDS, deeper ones in HBM, so that 16
   // waves leave room for the top of a deep tree (the most-visited ~1,100 nodes of a 21-level one).
@@ -1525,8 +1525,11 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   if (w * waveWords > total) return best;
   uint32_t k = (total - w * waveWords) / 8u;
   k = k < cap ? k : cap;
+  // (a PARTIAL top — a prefix of the area-ordered node array — costs the step a second load path;
+  // with the step as lean as it is now it pays from a few hundred nodes up: the 11.7 k-triangle
+  // mesh keeps 688 of its 6,003 nodes in LDS beside 16 waves, +1.8 %; 256 nodes +0.7 %)
   if (kEnv >= 0) k = (uint32_t)kEnv < k ? (uint32_t)kEnv : k;
-  else if (k < S.n_nodes) k = 0;
+  else if (k < S.n_nodes && k < 256u) k = 0;
   best = PersistPlan{w, k, waveWords, 4u * (8u * k + w * waveWords), 0};
   return best;
 }
