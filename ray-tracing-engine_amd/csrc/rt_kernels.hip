@@ -13,10 +13,15 @@
 //   * the photon k-NN keeps its k-heap in LDS ([slot][thread]) and re-uses the
 //     traversal stack region for the kd-tree's per-level split distances;
 //   * the pooled integrator (BVH direct lighting) runs as ONE persistent workgroup of 16
-//     waves per CU: its LDS holds the whole BVH when it fits plus every wave's private
-//     stack and ray pool, waves draw wave tiles from a global counter; after the tree copy
-//     no wave ever synchronises with another (wave-scope fences only), counters leave
-//     through one atomic per wave.
+//     waves per CU (fewer when deep stacks fill the LDS): its LDS holds every wave's private
+//     stack and ray pool plus the whole BVH when it fits, else its most-visited prefix;
+//     waves draw wave tiles from a global counter; after the tree copy no wave ever
+//     synchronises with another (wave-scope fences only), counters leave through one atomic
+//     per wave;
+//   * a wave issues one instruction of ANY kind per 4 cycles, so the hot loops are written for
+//     instruction COUNT: wave-uniform loops around predicated regions, lane masks made by hand
+//     (ballot / inverse ballot + scalar bit operations) where the compiler would add compares,
+//     and s_setprio by phase (the descent's dependent LDS round trips go first).
 // Built with -ffp-contract=off (bit parity with the x86-64 oracle, no FMA).
 #include <hip/hip_runtime.h>
 
