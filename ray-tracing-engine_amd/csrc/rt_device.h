@@ -119,10 +119,18 @@ RT_DEV void camera_ray(const rt_camera& c, float u, float v, f3& o, f3& d) {
 }
 
 // LightSource.h:46-49; first draw scales the horizontal axis (g++ evaluation order)
-RT_DEV f3 light_sample(Rng& g, const rt_light& l) {
-  float rh = g.uniformF(-l.side, l.side);
-  float rv = g.uniformF(-l.side, l.side);
+// (in two halves, so that a caller may keep the two parameters and form the point later)
+RT_DEV void light_sample_params(Rng& g, const rt_light& l, float& rh, float& rv) {
+  rh = g.uniformF(-l.side, l.side);
+  rv = g.uniformF(-l.side, l.side);
+}
+RT_DEV f3 light_point(const rt_light& l, float rh, float rv) {
   return ld(l.position) + (rv * ld(l.vertical)) + (rh * ld(l.horizontal));
+}
+RT_DEV f3 light_sample(Rng& g, const rt_light& l) {
+  float rh, rv;
+  light_sample_params(g, l, rh, rv);
+  return light_point(l, rh, rv);
 }
 // LightSource.h:51-54
 RT_DEV float light_radiance(const rt_light& l, f3 p) {

@@ -175,6 +175,12 @@ constexpr int LT_SS = 4;
 // LEAF phase costs 2 %); on the 1 M-triangle scene, where the waves wait on memory rather than on
 // each other, it costs 1 % — LT_NOPRIO (trees beyond kPrioMaxNodes) leaves everything at 0.
 constexpr int LT_NOPRIO = 8;
+// Compact ray pool (scenes whose stacks fill the LDS): per light the pool keeps the two
+// parameters of the light sample instead of the direction to it — 2 words instead of 3 per lane and
+// light, 768 B per wave with three lights — and the direction is rebuilt where it is needed by the
+// arithmetic light_sample() performs (LightSource.h:46-49, the same operations in the same order:
+// the same bits).  On the 1 M-triangle scene that is the sixteenth wave.
+constexpr int LT_COMPACT = 16;
 constexpr uint32_t kPrioMaxNodes = 65536;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
@@ -742,6 +748,15 @@ RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h
 constexpr int VP_PT = 0, VP_DIR = 192, VP_BDIR = VP_DIR + 192 * POOL_L, VP_KEY = VP_BDIR + 192, VP_LIST = VP_KEY + 128,
               VP_RES = VP_LIST + 32;
 constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
+constexpr int VP_COMPACT_SAVES = 64 * POOL_L;  // words a compact pool is shorter by
+// offsets of everything behind the per-light block, by layout
+template <bool CP> struct VpLayout {
+  static constexpr int PER_LIGHT = CP ? 128 : 192;
+  static constexpr int BDIR = VP_DIR + PER_LIGHT * POOL_L, KEY = BDIR + 192, LIST = KEY + 128, RES = LIST + 32;
+  static constexpr int WORDS = RES + 2 * POOL_L + 2;
+};
+static_assert(VpLayout<false>::WORDS == VP_WORDS && VpLayout<true>::WORDS == VP_WORDS - VP_COMPACT_SAVES, "pool layouts");
+static_assert(VpLayout<true>::KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 static_assert(VP_KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 static_assert(VP_WORDS == (int)rtbvh::kWavePoolWords && BLOCK == (int)rtbvh::kStackRowWords, "bvh_build.h sizes the depth cap with these");
 
@@ -750,13 +765,15 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
                       f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
                       uint32_t* over = nullptr) {
   const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
+  constexpr bool CP = (LT & LT_COMPACT) != 0;
+  using VP = VpLayout<CP>;
   float* fp = reinterpret_cast<float*>(pool);
   // 32 words: rank -> pixel lane (64 bytes) while rays are handed out; then rank -> victim
   // word while stealing (min(victims, free lanes) <= 32 entries)
-  uint32_t* list = pool + VP_LIST;
+  uint32_t* list = pool + VP::LIST;
   uint8_t* listB = reinterpret_cast<uint8_t*>(list);
-  uint32_t* res = pool + VP_RES;
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(pool + VP_KEY);
+  uint32_t* res = pool + VP::RES;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(pool + VP::KEY);
   const uint64_t amask = wave_ballot(alive);
   const uint32_t n = (uint32_t)__popcll(amask);
   f3 color = mk(0.f, 0.f, 0.f);
@@ -769,14 +786,20 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
     // draw order of the reference: the light samples in light order (Renderer.cpp:52),
     // then the hemisphere sample (Renderer.cpp:164)
     for (uint32_t l = 0; l < nl; l++) {
-      const f3 tl = light_sample(g, S.lights[l]) - point;
-      fp[VP_DIR + (3 * l + 0) * 64 + lane] = tl.x, fp[VP_DIR + (3 * l + 1) * 64 + lane] = tl.y, fp[VP_DIR + (3 * l + 2) * 64 + lane] = tl.z;
+      if (CP) {
+        float rh, rv;
+        light_sample_params(g, S.lights[l], rh, rv);
+        fp[VP_DIR + (2 * l + 0) * 64 + lane] = rh, fp[VP_DIR + (2 * l + 1) * 64 + lane] = rv;
+      } else {
+        const f3 tl = light_sample(g, S.lights[l]) - point;
+        fp[VP_DIR + (3 * l + 0) * 64 + lane] = tl.x, fp[VP_DIR + (3 * l + 1) * 64 + lane] = tl.y, fp[VP_DIR + (3 * l + 2) * 64 + lane] = tl.z;
+      }
     }
     if (bounce) {
       // (the caller's copy is read back from the pool after the loop: `point` and the bounce
       // direction do not occupy registers while the wave traverses)
       const f3 bd = hemisphere_sample(g, hitNormal);
-      fp[VP_BDIR + lane] = bd.x, fp[VP_BDIR + 64 + lane] = bd.y, fp[VP_BDIR + 128 + lane] = bd.z;
+      fp[VP::BDIR + lane] = bd.x, fp[VP::BDIR + 64 + lane] = bd.y, fp[VP::BDIR + 128 + lane] = bd.z;
       keys[lane] = ~0ull;
     }
     listB[lanes_below(amask)] = (uint8_t)lane;
@@ -871,8 +894,19 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
     }
     if (newRay) {
       const f3 pj = mk(fp[VP_PT + newJ], fp[VP_PT + 64 + newJ], fp[VP_PT + 128 + newJ]);
-      const uint32_t src = newK < nl ? VP_DIR + 192 * newK : VP_BDIR;
-      const f3 dj = mk(fp[src + newJ], fp[src + 64 + newJ], fp[src + 128 + newJ]);
+      f3 dj;
+      if (CP) {
+        if (newK < nl) {  // rebuild the direction from the light sample's two parameters
+          const rt_light& Lt = S.lights[newK];
+          const float rh = fp[VP_DIR + (2 * newK + 0) * 64 + newJ], rv = fp[VP_DIR + (2 * newK + 1) * 64 + newJ];
+          dj = light_point(Lt, rh, rv) - pj;
+        } else {
+          dj = mk(fp[VP::BDIR + newJ], fp[VP::BDIR + 64 + newJ], fp[VP::BDIR + 128 + newJ]);
+        }
+      } else {
+        const uint32_t src = newK < nl ? VP_DIR + 192 * newK : VP::BDIR;
+        dj = mk(fp[src + newJ], fp[src + 64 + newJ], fp[src + 128 + newJ]);
+      }
       T.start(pj, dj, S.invBoxScale);
       if (T.live()) T.cur = newNode;  // (a NaN ray stays dead)
       T.anyHit = newK < nl, T.pj = newJ, T.shared = newShared;
@@ -911,12 +945,13 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   // vertex read stale words nobody uses): nothing of them is live while the wave traverses
   const f3 pt = mk(fp[VP_PT + lane], fp[VP_PT + 64 + lane], fp[VP_PT + 128 + lane]);
   point = pt;
-  if (bounce) bdir = mk(fp[VP_BDIR + lane], fp[VP_BDIR + 64 + lane], fp[VP_BDIR + 128 + lane]);
+  if (bounce) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
   if (alive) {
     const BsdfBase base = bsdf_base(S.mats[mesh], hitNormal, -rayDir);  // the light-independent half, once
     for (uint32_t l = 0; l < nl; l++) {
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
-      const f3 toLight = mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
+      const f3 toLight = CP ? light_point(S.lights[l], fp[VP_DIR + (2 * l + 0) * 64 + lane], fp[VP_DIR + (2 * l + 1) * 64 + lane]) - pt
+                            : mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
       const f3 bsdf = bsdf_apply(base, toLight);
       const f3 radiance = light_eval(S.lights[l], pt);
       color = color + radiance * bsdf;
@@ -1497,6 +1532,7 @@ static bool allow_big_lds(K kernel, unsigned long long& done) {
 struct PersistPlan {
   uint32_t waves, topK, waveWords, ldsBytes;
   uint32_t ssRows;  // > 0: short stack (that many entries in LDS, the rest in HBM)
+  bool compact = false;  // LT_COMPACT pool layout
 };
 static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   const uint32_t total = rtbvh::kLdsWordsPerCU;  // words
@@ -1528,6 +1564,18 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   uint32_t w = wEnv > 0 ? (uint32_t)wEnv : 16u;
   while (w > 1u && w * waveWords > total) --w;
   if (w * waveWords > total) return best;
+  // big trees whose stacks leave fewer than 16 waves: the compact pool, if it buys a wave
+  static const int cpEnv = getenv("RT_COMPACT") ? atoi(getenv("RT_COMPACT")) : -1;
+  if (cpEnv != 0 && S.n_nodes > kPrioMaxNodes && w < 16u && kEnv < 0) {
+    const uint32_t ww = waveWords - (uint32_t)VP_COMPACT_SAVES;
+    uint32_t w2 = wEnv > 0 ? (uint32_t)wEnv : 16u;
+    while (w2 > 1u && w2 * ww > total) --w2;
+    if (w2 > w || cpEnv > 0) {
+      PersistPlan cp{w2, 0, ww, 4u * w2 * ww, 0};
+      cp.compact = true;
+      return cp;
+    }
+  }
   uint32_t k = (total - w * waveWords) / 8u;
   k = k < cap ? k : cap;
   // (a PARTIAL top — a prefix of the area-ordered node array — costs the step a second load path;
@@ -1567,7 +1615,10 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
                        counters);                                                                                       \
   } while (0)
       const int lt = P.topK == 0 ? LT_NONE : P.topK >= S.n_nodes ? LT_ALL : LT_TOP;
-      if (P.ssRows) {
+      if (P.compact) {
+        if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT);
+        else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT);
+      } else if (P.ssRows) {
         if (stats) {
           if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP | LT_SS);
           else RT_LAUNCH_PERSIST(true, LT_NONE | LT_SS);
