@@ -181,6 +181,11 @@ constexpr int LT_NOPRIO = 8;
 // arithmetic light_sample() performs (LightSource.h:46-49, the same operations in the same order:
 // the same bits).  On the 1 M-triangle scene that is the sixteenth wave.
 constexpr int LT_COMPACT = 16;
+// ... and without the bounce directions either (another 768 B per wave; implies LT_COMPACT): every
+// bounce ray is handed to its OWN pixel lane in the first hand-out and starts from the register that
+// holds the direction anyway; a lane that steals part of a bounce ray takes the direction from the
+// victim's registers.  The eight-million-triangle scene's sixteenth wave.
+constexpr int LT_COMPACT2 = 32;
 constexpr uint32_t kPrioMaxNodes = 65536;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
@@ -750,13 +755,14 @@ constexpr int VP_PT = 0, VP_DIR = 192, VP_BDIR = VP_DIR + 192 * POOL_L, VP_KEY =
 constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
 constexpr int VP_COMPACT_SAVES = 64 * POOL_L;  // words a compact pool is shorter by
 // offsets of everything behind the per-light block, by layout
-template <bool CP> struct VpLayout {
+template <int CP> struct VpLayout {  // CP = 0: full, 1: light parameters, 2: ... and no bounce directions
   static constexpr int PER_LIGHT = CP ? 128 : 192;
-  static constexpr int BDIR = VP_DIR + PER_LIGHT * POOL_L, KEY = BDIR + 192, LIST = KEY + 128, RES = LIST + 32;
+  static constexpr int BDIR = VP_DIR + PER_LIGHT * POOL_L, KEY = BDIR + (CP == 2 ? 0 : 192), LIST = KEY + 128, RES = LIST + 32;
   static constexpr int WORDS = RES + 2 * POOL_L + 2;
 };
-static_assert(VpLayout<false>::WORDS == VP_WORDS && VpLayout<true>::WORDS == VP_WORDS - VP_COMPACT_SAVES, "pool layouts");
-static_assert(VpLayout<true>::KEY % 2 == 0, "64-bit keys need 8-byte alignment");
+static_assert(VpLayout<0>::WORDS == VP_WORDS && VpLayout<1>::WORDS == VP_WORDS - VP_COMPACT_SAVES &&
+              VpLayout<2>::WORDS == VP_WORDS - 2 * VP_COMPACT_SAVES, "pool layouts");
+static_assert(VpLayout<1>::KEY % 2 == 0 && VpLayout<2>::KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 static_assert(VP_KEY % 2 == 0, "64-bit keys need 8-byte alignment");
 static_assert(VP_WORDS == (int)rtbvh::kWavePoolWords && BLOCK == (int)rtbvh::kStackRowWords, "bvh_build.h sizes the depth cap with these");
 
@@ -765,8 +771,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
                       f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
                       uint32_t* over = nullptr) {
   const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
-  constexpr bool CP = (LT & LT_COMPACT) != 0;
-  using VP = VpLayout<CP>;
+  constexpr bool CP2 = (LT & LT_COMPACT2) != 0, CP = CP2 || (LT & LT_COMPACT) != 0;
+  using VP = VpLayout<CP2 ? 2 : CP ? 1 : 0>;
   float* fp = reinterpret_cast<float*>(pool);
   // 32 words: rank -> pixel lane (64 bytes) while rays are handed out; then rank -> victim
   // word while stealing (min(victims, free lanes) <= 32 entries)
@@ -799,7 +805,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       // (the caller's copy is read back from the pool after the loop: `point` and the bounce
       // direction do not occupy registers while the wave traverses)
       const f3 bd = hemisphere_sample(g, hitNormal);
-      fp[VP::BDIR + lane] = bd.x, fp[VP::BDIR + 64 + lane] = bd.y, fp[VP::BDIR + 128 + lane] = bd.z;
+      if (CP2) bdir = bd;  // (stays in the caller's registers)
+      else fp[VP::BDIR + lane] = bd.x, fp[VP::BDIR + 64 + lane] = bd.y, fp[VP::BDIR + 128 + lane] = bd.z;
       keys[lane] = ~0ull;
     }
     listB[lanes_below(amask)] = (uint8_t)lane;
@@ -825,7 +832,21 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
     bool newRay = false, newShared = false;
     uint32_t newK = 0, newJ = 0;
     int32_t newNode = 0;
-    if (head < R) {
+    f3 dv = mk(0.f, 0.f, 0.f);  // (CP2) direction of the ray a thief joins, from the victim's registers
+    if (CP2 && bounce && head == 0) {
+      // first hand-out (every lane is free): each bounce ray to its own pixel lane, the first
+      // shadow rays to the lanes without a vertex — the same 64 ranks as below, dealt differently
+      if (alive) {
+        newRay = true, newK = nl, newJ = lane;
+      } else {
+        const uint32_t r = n + lanes_below(~amask);
+        if (r < R) {
+          const uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);  // >= 1 here
+          newRay = true, newK = k - 1u, newJ = listB[r - k * n];
+        }
+      }
+      head = 64;
+    } else if (head < R) {
       if (nIdle >= (int)S.refillT || nIdle == 64) {
         const uint32_t r = head + lanes_below(idle);
         if (!T.live() && r < R) {
@@ -882,6 +903,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
         const uint32_t w = thief ? (uint32_t)list16[q] : lane;
         const uint32_t v = w & 63u, e = w >> 6;
         const uint32_t kj = (uint32_t)__shfl((int)(myK | (myJ << 8)), (int)v, 64);  // (all lanes take part)
+        if (CP2) dv = mk(__shfl(T.d.x, (int)v, 64), __shfl(T.d.y, (int)v, 64), __shfl(T.d.z, (int)v, 64));
         if (thief) {
           uint32_t* slot = stackBase + (e + 1u) * BLOCK + v;  // (row 0 is the sentinel)
           newNode = (int32_t)*slot;
@@ -900,6 +922,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
           const rt_light& Lt = S.lights[newK];
           const float rh = fp[VP_DIR + (2 * newK + 0) * 64 + newJ], rv = fp[VP_DIR + (2 * newK + 1) * 64 + newJ];
           dj = light_point(Lt, rh, rv) - pj;
+        } else if (CP2) {
+          dj = newShared ? dv : bdir;  // a bounce ray: stolen (the victim's direction) or this lane's own
         } else {
           dj = mk(fp[VP::BDIR + newJ], fp[VP::BDIR + 64 + newJ], fp[VP::BDIR + 128 + newJ]);
         }
@@ -945,7 +969,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   // vertex read stale words nobody uses): nothing of them is live while the wave traverses
   const f3 pt = mk(fp[VP_PT + lane], fp[VP_PT + 64 + lane], fp[VP_PT + 128 + lane]);
   point = pt;
-  if (bounce) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
+  if (bounce && !CP2) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
   if (alive) {
     const BsdfBase base = bsdf_base(S.mats[mesh], hitNormal, -rayDir);  // the light-independent half, once
     for (uint32_t l = 0; l < nl; l++) {
@@ -1532,7 +1556,7 @@ static bool allow_big_lds(K kernel, unsigned long long& done) {
 struct PersistPlan {
   uint32_t waves, topK, waveWords, ldsBytes;
   uint32_t ssRows;  // > 0: short stack (that many entries in LDS, the rest in HBM)
-  bool compact = false;  // LT_COMPACT pool layout
+  int compact = 0;  // 1: LT_COMPACT pool layout, 2: LT_COMPACT2
 };
 static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   const uint32_t total = rtbvh::kLdsWordsPerCU;  // words
@@ -1567,12 +1591,19 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   // big trees whose stacks leave fewer than 16 waves: the compact pool, if it buys a wave
   static const int cpEnv = getenv("RT_COMPACT") ? atoi(getenv("RT_COMPACT")) : -1;
   if (cpEnv != 0 && S.n_nodes > kPrioMaxNodes && w < 16u && kEnv < 0) {
-    const uint32_t ww = waveWords - (uint32_t)VP_COMPACT_SAVES;
-    uint32_t w2 = wEnv > 0 ? (uint32_t)wEnv : 16u;
-    while (w2 > 1u && w2 * ww > total) --w2;
-    if (w2 > w || cpEnv > 0) {
-      PersistPlan cp{w2, 0, ww, 4u * w2 * ww, 0};
-      cp.compact = true;
+    // (the smallest step that buys the most waves; RT_COMPACT = 1 / 2 forces a level)
+    uint32_t bestW = w;
+    int level = 0;
+    for (int lv = 1; lv <= 2; ++lv) {
+      const uint32_t ww = waveWords - (uint32_t)(lv * VP_COMPACT_SAVES);
+      uint32_t w2 = wEnv > 0 ? (uint32_t)wEnv : 16u;
+      while (w2 > 1u && w2 * ww > total) --w2;
+      if (cpEnv > 0 ? lv == cpEnv : w2 > bestW) bestW = w2, level = lv;
+    }
+    if (level) {
+      const uint32_t ww = waveWords - (uint32_t)(level * VP_COMPACT_SAVES);
+      PersistPlan cp{bestW, 0, ww, 4u * bestW * ww, 0};
+      cp.compact = level;
       return cp;
     }
   }
@@ -1615,7 +1646,10 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
                        counters);                                                                                       \
   } while (0)
       const int lt = P.topK == 0 ? LT_NONE : P.topK >= S.n_nodes ? LT_ALL : LT_TOP;
-      if (P.compact) {
+      if (P.compact == 2) {
+        if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT2);
+        else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT2);
+      } else if (P.compact) {
         if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT);
         else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT);
       } else if (P.ssRows) {
