@@ -106,6 +106,8 @@ def pmc_measure(args):
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--accel", args.accel]
             if args.spp:
                 cmd += ["--spp", str(args.spp)]
+            # the child must run THIS run's kernel configuration (integrator, samples per wave, leaf size)
+            cmd += ["--integrator", args.integrator, "--lpp", str(args.lpp), "--leaf", str(args.leaf)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             rows = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -130,7 +132,7 @@ def pmc_child(args):
     kind, w, h, spp, mode, nph, k = WORKLOADS[args.workload]
     spp = args.spp or spp
     scene = pyrt.Scene(kind, w, h)
-    ctx = pyrt.Context(scene, device=0)
+    ctx = pyrt.Context(scene, device=0, bvh_leaf_max=args.leaf)
     params = build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, 0, 1)
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
     ctx.render_device(params, accum.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -250,7 +252,9 @@ def main():
     # counters of the timed kernel, measured now, by child processes, before this process
     # initialises the GPU (N = 1 only: the counters describe one GPU's launch)
     pmc, pmc_source = None, "skipped (--no-pmc)" if args.no_pmc else "not measured at N > 1"
-    if world_env == 1 and not args.no_pmc:
+    if args.integrator != "fused":
+        pmc_source = "skipped: the counters are defined for the fused kernel (the wavefront integrator is several kernels)"
+    elif world_env == 1 and not args.no_pmc:
         pmc, pmc_source = pmc_measure(args)
 
     import torch

@@ -18,7 +18,10 @@
  *   rt_knn                      <- kdtree::knearest (kdtree.h:180-195) test hook
  *
  * Conventions: plain C, int status (0 = RT_OK), caller-owned buffers, no C++
- * types or exceptions across the boundary, one host thread per context.  There
+ * types or exceptions across the boundary, one host thread per context and ONE LAUNCH IN
+ * FLIGHT per context: a context owns one work-queue head, one counter block and one
+ * wavefront state block, so rt_render_device / rt_trace_stream_device calls on the same
+ * context must be ordered on one stream (or synchronised) — use one context per stream.  There
  * is NO CPU fallback: every compute entry point fails with RT_ERR_NO_DEVICE if
  * no gfx950 device is usable.
  */
@@ -243,7 +246,11 @@ int rt_trace(rt_ctx* ctx, const rt_ray* rays, uint32_t n, uint32_t accel,
 /* RayTracer::rayTrace over a ray QUEUE resident in HBM (the trace stage of the wavefront
  * integrator; also a device-to-device form of rt_trace): ray_o[i] = origin xyz + kind bits
  * in w (bit 0: any-hit), ray_d[i] = direction xyz (float4 each); res[i] (uint2) = closest
- * hit {t bits, global triangle id} or {~0, ~0}, any-hit {0 / 1, 0}. */
+ * hit {t bits, global triangle id} or {~0, ~0}, any-hit {0 / 1, 0}.
+ * Unlike rt_trace this form has NO exhaustive-loop fallback for far origins: every ray goes
+ * through the BVH, so origins must lie within the range the padding covers (16 x max(|scene
+ * coordinate|, |camera|, |light position|)) — true of every ray an integrator generates
+ * (camera, surface points); the host cannot check device-resident rays. */
 int rt_trace_stream_device(rt_ctx* ctx, const void* d_ray_o, const void* d_ray_d, uint32_t n,
                            void* d_res, void* stream);
 int rt_knn(rt_ctx* ctx, const float* query3, uint32_t n, uint32_t k,

@@ -477,7 +477,13 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     }
     // trees deeper than the short stack's 12 LDS entries: overflow columns in HBM, one per lane of
     // every wave the persistent kernel can have in flight (numCUs x 16 waves x 32 rows x 256 B)
-    if (c->bvh.maxDepth > 1 &&
+    // (the short stack is opt-in, RT_SS=1: without it no launch plan selects LT_SS and the 32 MiB stay unallocated)
+    const char* ssEnv = getenv("RT_SS");
+    if (c->numCUs == 0) {
+      rt_destroy(c);
+      return fail(RT_ERR_HIP, "device %d reports no compute units", c->device);
+    }
+    if (ssEnv && atoi(ssEnv) != 0 && c->bvh.maxDepth > 1 &&
         hipMalloc(reinterpret_cast<void**>(&c->dSsOver), (size_t)c->numCUs * 16u * 32u * 64u * sizeof(uint32_t)) != hipSuccess) {
       rt_destroy(c);
       return fail(RT_ERR_HIP, "short-stack overflow allocation failed");
@@ -1086,6 +1092,9 @@ int rt_group_create(const rt_scene_desc* scene, const int32_t* devices, uint32_t
   bool distinct = true;
   for (uint32_t r = 0; r < n; ++r)
     for (uint32_t q = 0; q < r; ++q) distinct = distinct && devices[r] != devices[q];
+  // (sized before the first context exists: the failure path below runs rt_group_destroy ->
+  // group_free_frame, which walks these for every context created so far)
+  g->accum.assign(n, nullptr), g->packed.assign(n, nullptr), g->recv.assign(n, nullptr);
   for (uint32_t r = 0; r < n; ++r) {
     rt_options o{};
     if (opt) o = *opt;
@@ -1101,6 +1110,9 @@ int rt_group_create(const rt_scene_desc* scene, const int32_t* devices, uint32_t
       rc = fail(RT_ERR_HIP, "stream/event creation failed on device %d", devices[r]);
     if (rc != RT_OK) {
       const std::string keep = g_err;
+      // (the failing rank's own stream / event / context are not in the group yet)
+      if (s) (void)hipStreamDestroy(s);
+      if (e) (void)hipEventDestroy(e);
       if (c) rt_destroy(c);
       rt_group_destroy(g);
       g_err = keep;
@@ -1108,7 +1120,6 @@ int rt_group_create(const rt_scene_desc* scene, const int32_t* devices, uint32_t
     }
     g->ctx.push_back(c), g->dev.push_back(devices[r]), g->stream.push_back(s), g->packed_ready.push_back(e);
   }
-  g->accum.assign(n, nullptr), g->packed.assign(n, nullptr), g->recv.assign(n, nullptr);
   // exchange path: RCCL send/recv when every rank has its own device (ncclCommInitAll refuses
   // duplicates); ranks sharing a device (rehearsal on one GPU) use peer copies
   if (((n > 1 && distinct) || (n == 1 && getenv("RT_GROUP_FORCE_RCCL"))) && !getenv("RT_GROUP_NO_RCCL")) {

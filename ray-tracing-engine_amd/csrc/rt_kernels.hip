@@ -1379,7 +1379,8 @@ __global__ __launch_bounds__(BLOCK) void k_knn(DevScene S, const float* __restri
 // PhotonMap::PhotonMap + calculatePhotonPath (PhotonMap.h:14-50,92-155), one lane
 // per emitted photon, stream key (seed, RT_STREAM_PHOTON, light*perLight + j).
 // Each emitted photon stores at most ONE particle, so slot j of the output is
-// either that particle or flagged empty: order is deterministic (compacted on host).
+// either that particle or flagged empty: order is deterministic (stable compaction on the
+// device: kd_build.hip k_photon_compact, rt_build_photon_map; rt_emit_photons compacts on the host).
 template <bool BRUTE>
 __global__ __launch_bounds__(BLOCK) void k_emit(DevScene S, uint32_t perLight, uint32_t seed,
                                                 float4* __restrict__ outPos, float4* __restrict__ outDir,

@@ -97,19 +97,12 @@ class FrameAssembler:
                      if rank == 0 else None)
 
     def assemble(self, accum, stream=0):
+        """Every rank must call this the same number of times.  A failure (pack kernel, gather) is
+        raised, never papered over per rank: a rank that switched to another collective on its own
+        would leave the others waiting in the gather."""
         if self.world <= 1:
             return accum
-        if getattr(self, "fallback", False):
-            return reduce_frame(accum, dst=0)
-        try:
-            return self._gather(accum, stream)
-        except RuntimeError as e:  # a backend without gather: the reference exchange gives the same frame
-            if getattr(self, "calls", 0) > 0:
-                raise
-            import sys
-            sys.stderr.write("FrameAssembler: gather failed (%s); falling back to the full-frame SUM reduce\n" % e)
-            self.fallback = True
-            return reduce_frame(accum, dst=0)
+        return self._gather(accum, stream)
 
     def _gather(self, accum, stream):
         if self.cuda:

@@ -42,6 +42,19 @@ def test_group_frame_equals_single_context_frame(kind, w, h, spp, mode, ranks):
     g.close()
 
 
+def test_group_create_fails_cleanly_when_a_later_rank_has_no_device():
+    """a context at rank >= 1 that cannot be created (device ordinal out of range)
+    must surface as RtError — the failure path used to walk frame vectors not yet sized."""
+    s = pyrt.Scene("cubes", 32, 32)
+    for devs in ([0, 99], [0, 0, 99], [99]):
+        with pytest.raises(pyrt.RtError) as e:
+            pyrt.Group(s, devs)
+        assert e.value.code == 2 and "out of range" in str(e.value)  # RT_ERR_NO_DEVICE
+    g = pyrt.Group(s, [0, 0])  # the library is still usable afterwards
+    assert g.size == 2
+    g.close()
+
+
 def test_group_photon_frame_and_oracle():
     w, h, spp, nph, k = 48, 40, 2, 3000, 5
     s = pyrt.Scene("cubes", w, h)
