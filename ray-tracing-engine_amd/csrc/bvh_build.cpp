@@ -564,6 +564,135 @@ static void relayoutTop(std::vector<Node>& nodes, uint32_t kTop) {
   nodes.swap(out);
 }
 
+// ---------------------------------------------------------------- wide (4-ary) form
+namespace {
+struct Collapser {
+  Built& b;
+  std::vector<Node4x16>& out;
+  std::vector<uint8_t> height;  // stack entries the BINARY subtree below a node can need (a node over two leaves: 1)
+  uint32_t maxNeed = 0;
+  double rootArea = 0;
+
+  struct Cand {
+    int32_t ref;
+    float lo[3], hi[3];
+    float area() const {
+      const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+      return dx * dy + dy * dz + dz * dx;
+    }
+  };
+  static Cand childOf(const Node& n, int i) {
+    Cand c;
+    c.ref = n.child[i];
+    for (int a = 0; a < 3; ++a) c.lo[a] = i ? n.lo1[a] : n.lo0[a], c.hi[a] = i ? n.hi1[a] : n.hi0[a];
+    return c;
+  }
+  int need(int32_t ref) const { return ref < 0 ? 0 : height[ref]; }
+
+  void computeHeights() {
+    height.assign(b.nodes.size(), 0);
+    // children may sit before or after their parent (relayoutTop): explicit post-order
+    std::vector<std::pair<int32_t, int>> st;
+    st.push_back({0, 0});
+    while (!st.empty()) {
+      auto& top = st.back();
+      const Node& nd = b.nodes[top.first];
+      if (top.second < 2) {
+        const int32_t c = nd.child[top.second++];
+        if (c >= 0) st.push_back({c, 0});
+      } else {
+        height[top.first] = (uint8_t)(1 + std::max(need(nd.child[0]), need(nd.child[1])));
+        st.pop_back();
+      }
+    }
+  }
+
+  // emits the wide node that replaces binary node `idx`; `budget` = stack entries still available
+  // to this subtree, `used` = entries already on the stack when a ray arrives here
+  uint32_t emit(int32_t idx, int budget, int used, double pHere) {
+    Cand c[4];
+    int k = 2;
+    c[0] = childOf(b.nodes[idx], 0), c[1] = childOf(b.nodes[idx], 1);
+    while (k < 4) {
+      int pick = -1;
+      float bestA = -1.f;
+      for (int i = 0; i < k; ++i) {
+        if (c[i].ref < 0) continue;
+        // with k + 1 children a visit pushes up to k entries: every child's own need must still fit
+        bool ok = true;
+        for (int j = 0; j < k && ok; ++j)
+          if (j != i) ok = k + need(c[j].ref) <= budget;
+        const Node& g = b.nodes[c[i].ref];
+        ok = ok && k + need(g.child[0]) <= budget && k + need(g.child[1]) <= budget;
+        if (ok && c[i].area() > bestA) bestA = c[i].area(), pick = i;
+      }
+      if (pick < 0) break;
+      const Node& g = b.nodes[c[pick].ref];
+      c[pick] = childOf(g, 0);
+      c[k++] = childOf(g, 1);
+    }
+    const uint32_t self = (uint32_t)out.size();
+    out.emplace_back();
+    maxNeed = std::max<uint32_t>(maxNeed, (uint32_t)(used + k - 1));
+    b.visitCost4 += pHere;
+    int32_t refs[4];
+    for (int i = 0; i < k; ++i) {
+      if (c[i].ref >= 0) {
+        const double pc = rootArea > 0 ? std::min(1.0, (double)c[i].area() / rootArea) : 1.0;
+        const uint32_t w = emit(c[i].ref, budget - (k - 1), used + k - 1, pc);
+        if (w >= (1u << 25)) throw std::runtime_error("wide node offsets exceed 31 bits");
+        refs[i] = (int32_t)(w * 64u);
+      } else {
+        const uint32_t code = ~(uint32_t)c[i].ref;
+        refs[i] = (int32_t)~((code >> 3) * 48u | (code & 7u));
+      }
+    }
+    Node4x16& q = out[self];
+    for (int i = 0; i < 4; ++i) {
+      if (i < k) {
+        for (int a = 0; a < 3; ++a) {
+          q.box[i][2 * a] = toHalfDirected(c[i].lo[a] * b.boxScale, false);
+          q.box[i][2 * a + 1] = toHalfDirected(c[i].hi[a] * b.boxScale, true);
+          if (halfToFloat(q.box[i][2 * a]) > c[i].lo[a] * b.boxScale || halfToFloat(q.box[i][2 * a + 1]) < c[i].hi[a] * b.boxScale)
+            throw std::runtime_error("internal error: packed wide box does not contain the float box");
+        }
+        q.child[i] = refs[i];
+      } else {
+        for (int a = 0; a < 3; ++a) q.box[i][2 * a] = 0x7bffu, q.box[i][2 * a + 1] = 0xfbffu;  // +65504 / -65504
+        q.child[i] = refs[0];
+      }
+    }
+    return self;
+  }
+};
+}  // namespace
+
+void collapse4(Built& b, uint32_t stackBudget) {
+  b.nodes4.clear(), b.stackNeed4 = 0, b.visitCost2 = b.visitCost4 = 0;
+  if (b.nodes.empty()) return;
+  Collapser C{b, b.nodes4};
+  C.computeHeights();
+  {
+    Box r;
+    r.reset();
+    const Node& n0 = b.nodes[0];
+    r.grow(n0.lo0), r.grow(n0.hi0), r.grow(n0.lo1), r.grow(n0.hi1);
+    C.rootArea = r.halfArea();
+  }
+  const int budget = std::max<int>(C.height[0], (int)stackBudget);
+  if (budget + 3 > kMaxDepth + 8) throw std::runtime_error("wide BVH stack budget out of range");
+  b.nodes4.reserve(b.nodes.size() / 2 + 16);
+  C.emit(0, budget, 0, 1.0);
+  b.stackNeed4 = C.maxNeed;
+  // the binary tree's estimate of node visits per random ray, for the report: the root plus every
+  // inner child by its box area
+  double v2 = 1.0;
+  for (const Node& n : b.nodes)
+    for (int i = 0; i < 2; ++i)
+      if (n.child[i] >= 0) v2 += std::min(1.0, (double)Collapser::childOf(n, i).area() / std::max(C.rootArea, 1e-300));
+  b.visitCost2 = v2;
+}
+
 void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threads) {
   if (leafMax == 0) leafMax = 2;  // measured on C2: 2 -> 7.35, 3 -> 7.26, 4 -> 6.63, 8 -> 4.9 Grays/s
   if (leafMax > 8) leafMax = 8;

@@ -50,6 +50,21 @@ struct alignas(16) Node16 {  // 32 B
 };
 static_assert(sizeof(Node16) == 32, "packed node record must be 32 bytes");
 
+// The WIDE form (round 3): up to four children per record — the binary SAH tree collapsed (an inner
+// child is replaced by its own two children, largest box first) — so that a ray makes about half as
+// many DEPENDENT node fetches: on scenes that do not fit the caches a wave's traversal step costs
+// the miss latency of its slowest lane whatever the record holds, and halving the steps is what
+// shortens the frame.  Same plane encoding as Node16 (binary16 of coordinate * boxScale, rounded
+// outward, (lo, hi) pairs per axis), same child refs; one 64-byte record = half a cache line, never
+// straddling one.  Unused slots hold an inverted box (lo = +65504, hi = -65504: no finite ray
+// enters it) and a copy of slot 0's ref, so that even a degenerate ray that "hits" one walks a
+// valid subtree twice instead of a wild pointer.
+struct alignas(64) Node4x16 {  // 64 B
+  uint16_t box[4][6];          // box[c][2 * axis] = lo, box[c][2 * axis + 1] = hi
+  int32_t child[4];            // >= 0: BYTE offset of the child's record (index * 64); < 0: leaf, as Node16
+};
+static_assert(sizeof(Node4x16) == 64, "wide node record must be 64 bytes");
+
 struct alignas(16) TriRec { // 48 B
   float p0[3], e1[3], e2[3];
   uint32_t id;              // global triangle index in reference (mesh, tri) order
@@ -103,7 +118,16 @@ struct Built {
   uint32_t maxDepth = 0, leafMax = 2;
   float pad = 0.f;
   float originBound = 0.f;      // ray origins with a larger |coordinate| are outside the padding analysis
+  // wide form of the same tree (collapse4): empty unless requested
+  std::vector<Node4x16> nodes4;
+  uint32_t stackNeed4 = 0;      // most entries a lane's traversal stack can hold on this wide tree
+  double visitCost2 = 0, visitCost4 = 0;  // SAH estimate of node visits per random ray, binary / wide
 };
+// Collapses b.nodes (binary, float boxes) into b.nodes4.  `stackBudget` bounds the stack entries any
+// root-to-leaf path can pile up (a 4-wide node pushes up to three): merges that would exceed it on a
+// deep path are not made, so the LDS stack of the render kernel stays as small as the binary tree's.
+// 0 = the binary tree's own need (its depth).
+void collapse4(Built& b, uint32_t stackBudget = 0);
 
 // What both builders (host: build(); device: csrc/bvh_gpu.hip) derive from the scene
 // before touching a triangle: validation (throws std::runtime_error on an inconsistent

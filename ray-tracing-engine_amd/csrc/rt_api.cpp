@@ -294,6 +294,8 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   }
   // (+1: row 0 of a lane's stack is the TERM sentinel, rt_kernels.hip Trav)
   A.stackLevels = (levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels) + 1u;
+  // the wide tree: its own stack need + the sentinel row + the two rows a step writes ahead of the top
+  A.stackLevelsWide = (c->bvh.stackNeed4 > 1 ? c->bvh.stackNeed4 : 1u) + 3u;
   A.tileCounter = c->dTileCounter, A.numCUs = c->numCUs, A.waveWords = 0;
   A.ssOver = c->dSsOver;
   const int e = c->evUsed % kEventPairs;
@@ -410,6 +412,19 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     } else {
       rtbvh::build(*sc, opt ? opt->bvh_leaf_max : 0, c->bvh);
     }
+    // the wide (4-ary) form: OPT-IN (rt_options.bvh_width = 4 or RT_BVH_WIDE=1; host-built trees only).
+    // Measured on MI355X: 0.71x the node visits but 4 instead of 2 vector-memory
+    // requests per visit, and the CU's vector L1 — which serves ~0.7-0.9 divergent 16-B requests per
+    // clock whatever their hit level — is what binds the big scenes: 1 M triangles 407 vs 357 ms.
+    if (!gpuBuild && c->bvh.nodes4.empty()) {
+      const char* we = getenv("RT_BVH_WIDE");
+      const uint32_t width = opt ? opt->bvh_width : 0;
+      const bool wide = we ? atoi(we) != 0 : width == 4;
+      if (wide) {
+        const char* wb = getenv("RT_BVH_WIDE_BUDGET");
+        rtbvh::collapse4(c->bvh, wb ? (uint32_t)atoi(wb) : 0u);
+      }
+    }
   } catch (const std::exception& e) {
     delete c;
     return fail(RT_ERR_INVALID, "scene rejected: %s", e.what());
@@ -445,6 +460,9 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     c->builder = RT_BVH_DEVICE;
   } else {
     UP(nodes, c->bvh.nodes16.data(), c->bvh.nodes16.size() * 2);
+    static_assert(sizeof(rtbvh::Node4x16) == 4 * sizeof(uint4), "wide node layout");
+    UP(nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4);
+    S.n_nodes4 = static_cast<uint32_t>(c->bvh.nodes4.size());
     UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);
     UP(trisRef, c->bvh.trisRef.data(), c->bvh.trisRef.size() * 3);
     S.n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
@@ -761,6 +779,7 @@ int rt_bvh_info_get(rt_ctx* c, rt_bvh_info* out) {
   out->pad = c->bvh.pad;
   out->build_ms = c->buildMs;
   out->builder = c->builder;
+  out->n_wide_nodes = c->S.n_nodes4;
   return RT_OK;
 }
 
@@ -798,6 +817,87 @@ int rt_bvh_build_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t threa
     *digest = h;
   } catch (const std::exception& e) {
     return fail(RT_ERR_INVALID, "BVH build failed: %s", e.what());
+  }
+  return RT_OK;
+}
+
+int rt_bvh_wide_check_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t stack_budget, uint32_t* out8, double* est2) {
+  if (!sc || !out8) return fail(RT_ERR_INVALID, "null argument");
+  try {
+    rtbvh::Built b;
+    rtbvh::build(*sc, leaf_max, b, 0);
+    rtbvh::collapse4(b, stack_budget);
+    const size_t nw = b.nodes4.size();
+    if (nw == 0) return fail(RT_ERR_STATE, "collapse produced no nodes");
+    const float inv = 1.f / b.boxScale;
+    std::vector<uint32_t> seen(b.tris.size(), 0);
+    uint32_t kcount[5] = {0, 0, 0, 0, 0};
+    uint32_t maxStack = 0;
+    std::vector<uint8_t> visited(nw, 0);
+    // depth-first over the wide tree; returns the float box of everything below a child ref
+    struct Bx { float lo[3], hi[3]; };
+    struct Walker {
+      const rt_scene_desc& sc; const rtbvh::Built& b; std::vector<uint32_t>& seen; std::vector<uint8_t>& visited;
+      uint32_t* kcount; uint32_t& maxStack; float inv; std::string err;
+      Bx walk(int32_t ref, uint32_t used) {
+        Bx r;
+        for (int a = 0; a < 3; ++a) r.lo[a] = 3e38f, r.hi[a] = -3e38f;
+        if (ref < 0) {  // leaf: ~(byte offset of the first record | count - 1)
+          const uint32_t code = ~(uint32_t)ref, cnt = (code & 7u) + 1u, first = (code & ~7u) / 48u;
+          if ((code & ~7u) % 48u) err = "leaf offset is not a multiple of 48";
+          for (uint32_t i = first; i < first + cnt && err.empty(); ++i) {
+            if (i >= seen.size()) { err = "leaf range beyond the triangle array"; break; }
+            seen[i]++;
+            const uint32_t id = b.tris[i].id;
+            for (int k = 0; k < 3; ++k) {
+              const float* q = sc.vertex_pos + 3 * (size_t)sc.tri_vtx[3 * (size_t)id + k];
+              for (int a = 0; a < 3; ++a) r.lo[a] = std::min(r.lo[a], q[a]), r.hi[a] = std::max(r.hi[a], q[a]);
+            }
+          }
+          return r;
+        }
+        if (ref % 64) { err = "inner ref is not a multiple of 64"; return r; }
+        const uint32_t idx = (uint32_t)ref / 64u;
+        if (idx >= visited.size()) { err = "inner ref beyond the node array"; return r; }
+        if (visited[idx]++) { err = "wide node reached twice"; return r; }
+        const rtbvh::Node4x16& n = b.nodes4[idx];
+        int k = 0;
+        while (k < 4 && !(n.box[k][0] == 0x7bffu && n.box[k][1] == 0xfbffu)) ++k;
+        for (int i = k; i < 4; ++i) {
+          for (int a = 0; a < 3; ++a)
+            if (n.box[i][2 * a] != 0x7bffu || n.box[i][2 * a + 1] != 0xfbffu) err = "unused slot is not the inverted box";
+          if (n.child[i] != n.child[0]) err = "unused slot does not repeat slot 0's ref";
+        }
+        if (k < 2) err = "wide node with fewer than two children";
+        kcount[k]++;
+        maxStack = std::max(maxStack, used + (uint32_t)k - 1u);
+        for (int i = 0; i < k && err.empty(); ++i) {
+          const Bx c = walk(n.child[i], used + (uint32_t)k - 1u);
+          for (int a = 0; a < 3; ++a) {
+            const float lo = rtbvh::halfToFloat(n.box[i][2 * a]) * inv, hi = rtbvh::halfToFloat(n.box[i][2 * a + 1]) * inv;
+            // the stored box must contain the geometry below it, padded
+            if (!(lo <= c.lo[a] - 0.999f * b.pad && hi >= c.hi[a] + 0.999f * b.pad)) err = "a wide child box does not contain its padded geometry";
+            r.lo[a] = std::min(r.lo[a], c.lo[a]), r.hi[a] = std::max(r.hi[a], c.hi[a]);
+          }
+        }
+        return r;
+      }
+    } W{*sc, b, seen, visited, kcount, maxStack, inv, {}};
+    W.walk(0, 0);
+    if (!W.err.empty()) return fail(RT_ERR_STATE, "wide BVH check: %s", W.err.c_str());
+    // (a one-triangle scene has that triangle under both children of its root: bvh_build.cpp build())
+    for (uint32_t v : seen)
+      if (v != 1 && !(sc->n_triangles == 1 && v == 2)) return fail(RT_ERR_STATE, "wide BVH check: a triangle record is referenced %u times", v);
+    for (uint8_t v : visited)
+      if (v != 1) return fail(RT_ERR_STATE, "wide BVH check: an unreachable wide node");
+    if (maxStack != b.stackNeed4) return fail(RT_ERR_STATE, "wide BVH check: stack need %u, builder says %u", maxStack, b.stackNeed4);
+    const uint32_t allowed = std::max(stack_budget, b.maxDepth);
+    if (maxStack > allowed) return fail(RT_ERR_STATE, "wide BVH check: stack need %u exceeds the budget %u", maxStack, allowed);
+    out8[0] = (uint32_t)b.nodes.size(), out8[1] = (uint32_t)nw, out8[2] = b.stackNeed4, out8[3] = b.maxDepth;
+    out8[4] = kcount[4], out8[5] = kcount[3], out8[6] = kcount[2], out8[7] = 0;
+    if (est2) est2[0] = b.visitCost2, est2[1] = b.visitCost4;
+  } catch (const std::exception& e) {
+    return fail(RT_ERR_INVALID, "wide BVH check failed: %s", e.what());
   }
   return RT_OK;
 }

@@ -29,6 +29,7 @@ namespace rtk {
 // Device-resident flattened scene (all pointers are HBM allocations of rt_ctx).
 struct DevScene {
   const uint4* nodes;      // n_nodes x 32 B: 12 x f16 box planes ((lo, hi) per axis, child 0 then child 1, scaled) + 2 child refs
+  const uint4* nodes4;     // wide form of the same tree (rtbvh::Node4x16, n_nodes4 x 64 B: 4 x 6 f16 planes + 4 refs), or null
   const float4* tris;      // n_tris x 48 B, BVH leaf order: {p0,e1.x}{e1.yz,e2.xy}{e2.z,id,mesh,-}
   const float4* trisRef;   // same records in reference (mesh,tri) order (brute-force path)
   const uint4* triShade;   // per global triangle id: {v0,v1,v2 (global vertex ids), mesh}
@@ -41,6 +42,7 @@ struct DevScene {
   const float4* phPos;     // photons in kd-tree order: xyz + pad
   const float4* phDir;     // income direction xyz + weight
   uint32_t n_tris, n_nodes, n_lights, n_photons;
+  uint32_t n_nodes4;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
   uint32_t topK;           // node records [0, topK) are LDS-resident in the persistent kernel (set per launch)
   // short stack (pooled persistent kernel on deep trees; set per launch)
@@ -60,6 +62,7 @@ struct RenderArgs {
   uint32_t width, height, spp, s0, s1, mode, max_depth, seed, k, photons_requested;
   uint32_t flags;         // bit 0: shadow rays through the wave-level pool
   uint32_t stackLevels;   // LDS traversal-stack entries per lane (BVH depth; kd depth + 1 with photons)
+  uint32_t stackLevelsWide;  // the same for the wide tree (its stack need + the sentinel row + 2 rows the step writes ahead)
   uint32_t sshift;        // a wave = (64 >> sshift) pixels x (1 << sshift) samples side by side
   uint32_t tileW, tileH;  // pixel footprint of one wave (tileW * tileH == 64 >> sshift)
   // persistent pooled kernel (k_render_persist)

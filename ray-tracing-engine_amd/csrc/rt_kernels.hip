@@ -186,6 +186,10 @@ constexpr int LT_COMPACT = 16;
 // holds the direction anyway; a lane that steals part of a bounce ray takes the direction from the
 // victim's registers.  The eight-million-triangle scene's sixteenth wave.
 constexpr int LT_COMPACT2 = 32;
+// WIDE nodes (rtbvh::Node4x16): one 64-B record with four child boxes per step; the hit children are
+// sorted by entry distance, the nearest is entered, the others pushed far to near.  Half the DEPENDENT
+// fetches per ray: the lever on scenes whose nodes come from L2 / HBM.
+constexpr int LT_WIDE = 64;
 constexpr uint32_t kPrioMaxNodes = 65536;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
@@ -195,6 +199,8 @@ struct Trav {
   static constexpr int LT = LTX & 3;
   static constexpr bool SS = (LTX & LT_SS) != 0;
   static constexpr bool PRIO = (LTX & LT_NOPRIO) == 0;
+  static constexpr bool WIDE = (LTX & LT_WIDE) != 0;
+  static_assert(!WIDE || (LT == LT_NONE && !SS), "wide nodes are fetched from HBM/L2 and use the plain LDS stack");
   f3 o, d, inv, oi;
   uint32_t rotX, rotY, rotZ;  // 16 where the direction component is negative (order_planes)
   float best;
@@ -273,6 +279,9 @@ struct Trav {
     if (PRIO) __builtin_amdgcn_s_setprio(2);
     if (inner) for (;;) {
      if (__builtin_amdgcn_inverse_ballot_w64(inner)) {
+      if constexpr (WIDE) {
+        step_wide<STATS>(S, st, statWait, statIdle);
+      } else {
       // 32-B packed node: 12 x f16 planes + 2 refs (32-bit byte offset from a uniform base:
       // the load takes the base from SGPRs)
       uint4 a, b;
@@ -342,6 +351,7 @@ struct Trav {
       // (only when the lanes that would otherwise wait clearly outnumber them: in the
       // tail of a pool, with a handful of live rays, a round must not shrink to one step)
       // (desc < leafT and 3 * desc < live0, folded into one threshold)
+      }
      }
       inner = __builtin_amdgcn_ballot_w64(cur >= 0);
       if (__popcll(inner) < exitBelow) break;
@@ -370,6 +380,63 @@ struct Trav {
     }
     if (PRIO && MODE == TRAV_MIXED) __builtin_amdgcn_s_setprio(1);  // back in the pool loop
     PH(PH_LEAF);
+  }
+
+  // One step on a WIDE node (rtbvh::Node4x16): four slab tests on one 64-B record (4 x dwordx4 from
+  // one half cache line), the hit children ordered by entry distance with a five-comparator network
+  // (key = entry distance, -1 for a miss: descending order puts the hits first, far to near), the
+  // three farthest stored unconditionally above the top (rows the stack is sized for; a row that is
+  // not claimed is simply overwritten later), the nearest entered.  No hit: pop, as in the binary step.
+  template <bool STATS>
+  RT_DEV void step_wide(const DevScene& S, LaneStats& st, uint32_t statWait, uint32_t statIdle) {
+    const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes4) + (uint32_t)cur);
+    const uint4 a = n[0], b = n[1], c = n[2], r = n[3];
+    PHC(PH_N_STEPS);
+    const int32_t below = (int32_t)peek();
+    if (STATS) {
+      st.nodes++;
+      if (__ffsll((long long)wave_ballot(true)) - 1 == (int)(threadIdx.x & 63)) st.wnode++, st.lwait += statWait, st.lidle += statIdle;
+    }
+    // child 0: a.x a.y a.z | child 1: a.w b.x b.y | child 2: b.z b.w c.x | child 3: c.y c.z c.w
+    float k0, k1, k2, k3;
+    {
+      const uint32_t x = order_planes(a.x, rotX), y = order_planes(a.y, rotY), z = order_planes(a.z, rotZ);
+      const bool h = slab_ordered(h2f_lo(x), h2f_hi(x), h2f_lo(y), h2f_hi(y), h2f_lo(z), h2f_hi(z), inv, oi, best, k0);
+      k0 = h ? k0 : -1.f;
+    }
+    {
+      const uint32_t x = order_planes(a.w, rotX), y = order_planes(b.x, rotY), z = order_planes(b.y, rotZ);
+      const bool h = slab_ordered(h2f_lo(x), h2f_hi(x), h2f_lo(y), h2f_hi(y), h2f_lo(z), h2f_hi(z), inv, oi, best, k1);
+      k1 = h ? k1 : -1.f;
+    }
+    {
+      const uint32_t x = order_planes(b.z, rotX), y = order_planes(b.w, rotY), z = order_planes(c.x, rotZ);
+      const bool h = slab_ordered(h2f_lo(x), h2f_hi(x), h2f_lo(y), h2f_hi(y), h2f_lo(z), h2f_hi(z), inv, oi, best, k2);
+      k2 = h ? k2 : -1.f;
+    }
+    {
+      const uint32_t x = order_planes(c.y, rotX), y = order_planes(c.z, rotY), z = order_planes(c.w, rotZ);
+      const bool h = slab_ordered(h2f_lo(x), h2f_hi(x), h2f_lo(y), h2f_hi(y), h2f_lo(z), h2f_hi(z), inv, oi, best, k3);
+      k3 = h ? k3 : -1.f;
+    }
+    uint32_t r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
+#define RT_CSWAP(ka, ra, kb, rb)                       \
+  do {                                                 \
+    const bool sw_ = ka < kb;                          \
+    const float kx_ = sw_ ? kb : ka, ky_ = sw_ ? ka : kb; \
+    const uint32_t rx_ = sw_ ? rb : ra, ry_ = sw_ ? ra : rb; \
+    ka = kx_, kb = ky_, ra = rx_, rb = ry_;            \
+  } while (0)
+    RT_CSWAP(k0, r0, k1, r1);
+    RT_CSWAP(k2, r2, k3, r3);
+    RT_CSWAP(k0, r0, k2, r2);
+    RT_CSWAP(k1, r1, k3, r3);
+    RT_CSWAP(k1, r1, k2, r2);
+#undef RT_CSWAP
+    top[BLOCK] = r0, top[2 * BLOCK] = r1, top[3 * BLOCK] = r2;
+    const bool e0 = k0 >= 0.f, e1 = k1 >= 0.f, e2 = k2 >= 0.f, e3 = k3 >= 0.f;
+    cur = e3 ? (int32_t)r3 : e2 ? (int32_t)r2 : e1 ? (int32_t)r1 : e0 ? (int32_t)r0 : below;
+    top += e3 ? 3 * BLOCK : e2 ? 2 * BLOCK : e1 ? BLOCK : e0 ? 0 : -BLOCK;  // (a lane that pops the sentinel is dead until start())
   }
 
   // The first two records of a leaf at once and without a branch: both tests run, every
@@ -1327,10 +1394,10 @@ __global__ void k_unpack_owned(const float4* __restrict__ packed, float4* __rest
 }
 
 // ---------------------------------------------------------------- test hooks
-template <bool BRUTE, bool ANY>
+template <bool BRUTE, bool ANY, int LT = LT_NONE>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, const rt_ray* __restrict__ rays, uint32_t n,
                                                  rt_hit* __restrict__ hits, unsigned long long* counters) {
-  __shared__ uint32_t lds[(STACK + 1) * BLOCK];
+  __shared__ uint32_t lds[(STACK + 3) * BLOCK];  // (+1 sentinel row, +2 rows a wide step writes ahead)
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   LaneStats st;
   if (i < n) {
@@ -1341,7 +1408,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, const rt_ray* __res
     // take the exhaustive loop (a NaN origin compares false and stays on the BVH path,
     // which ends it at once)
     const bool far = !BRUTE && fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) > S.originBound;
-    bool found = cast<BRUTE, ANY, true>(S, !far, o, d, lds + threadIdx.x, h, st);
+    bool found = cast<BRUTE, ANY, true, LT>(S, !far, o, d, lds + threadIdx.x, h, st);
     if (far) found = brute<ANY, true>(S, o, d, h, st);
     rt_hit r;
     r.hit = found, r.mesh = 0, r.tri = 0, r.vtx[0] = r.vtx[1] = r.vtx[2] = 0, r.u = r.v = r.d = 0.f;
@@ -1559,9 +1626,9 @@ struct PersistPlan {
   uint32_t ssRows;  // > 0: short stack (that many entries in LDS, the rest in HBM)
   int compact = 0;  // 1: LT_COMPACT pool layout, 2: LT_COMPACT2
 };
-static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
+static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A, bool wide) {
   const uint32_t total = rtbvh::kLdsWordsPerCU;  // words
-  const uint32_t waveWords = A.stackLevels * BLOCK + VP_WORDS;
+  const uint32_t waveWords = (wide ? A.stackLevelsWide : A.stackLevels) * BLOCK + VP_WORDS;
   static const int wEnv = getenv("RT_PERSIST_WAVES") ? atoi(getenv("RT_PERSIST_WAVES")) : 0;
   static const int kEnv = getenv("RT_TOPK") ? atoi(getenv("RT_TOPK")) : -1;
   const uint32_t cap = S.n_nodes < rtbvh::kTopNodes ? S.n_nodes : rtbvh::kTopNodes;
@@ -1578,7 +1645,7 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   const bool deep = false;
   static const int ssRowsEnv = getenv("RT_SS_ROWS") ? atoi(getenv("RT_SS_ROWS")) : 12;  // (tests force it small)
   const uint32_t ssRowsWanted = ssRowsEnv < 1 ? 1u : (uint32_t)ssRowsEnv;
-  if (A.ssOver && (ssEnv >= 0 ? ssEnv != 0 : deep) && A.stackLevels - 1u > ssRowsWanted) {
+  if (!wide && A.ssOver && (ssEnv >= 0 ? ssEnv != 0 : deep) && A.stackLevels - 1u > ssRowsWanted) {
     const uint32_t rows = ssRowsWanted, ww = (rows + 1u) * BLOCK + VP_WORDS;
     uint32_t w2 = wEnv > 0 ? (uint32_t)wEnv : 16u;
     uint32_t k2 = (total - w2 * ww) / 8u;
@@ -1591,7 +1658,7 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   if (w * waveWords > total) return best;
   // big trees whose stacks leave fewer than 16 waves: the compact pool, if it buys a wave
   static const int cpEnv = getenv("RT_COMPACT") ? atoi(getenv("RT_COMPACT")) : -1;
-  if (cpEnv != 0 && S.n_nodes > kPrioMaxNodes && w < 16u && kEnv < 0) {
+  if (cpEnv != 0 && (S.n_nodes > kPrioMaxNodes || wide) && w < 16u && (kEnv < 0 || wide)) {
     // (the smallest step that buys the most waves; RT_COMPACT = 1 / 2 forces a level)
     uint32_t bestW = w;
     int level = 0;
@@ -1608,6 +1675,7 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
       return cp;
     }
   }
+  if (wide) return PersistPlan{w, 0, waveWords, 4u * w * waveWords, 0};  // (wide records are not copied into LDS)
   uint32_t k = (total - w * waveWords) / 8u;
   k = k < cap ? k : cap;
   // (a PARTIAL top — a prefix of the area-ordered node array — costs the step a second load path;
@@ -1626,11 +1694,13 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   if (blocks == 0) return hipSuccess;
   static const bool noPersist = getenv("RT_NO_PERSIST") != nullptr;
   if (POOLED && !noPersist && A.tileCounter && A.numCUs) {
-    const PersistPlan P = plan_persist(S, A);
+    const bool wide = S.nodes4 != nullptr;
+    const PersistPlan P = plan_persist(S, A, wide);
     if (P.waves) {
       DevScene S2 = S;
       RenderArgs A2 = A;
       S2.topK = P.topK, A2.waveWords = P.waveWords;
+      if (wide) A2.stackLevels = A.stackLevelsWide;
       if (P.ssRows) {
         S2.ssRows = P.ssRows, S2.ssOver = A.ssOver, S2.ssOvRows = 32u;
         A2.stackLevels = P.ssRows + 1u;
@@ -1647,7 +1717,18 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
                        counters);                                                                                       \
   } while (0)
       const int lt = P.topK == 0 ? LT_NONE : P.topK >= S.n_nodes ? LT_ALL : LT_TOP;
-      if (P.compact == 2) {
+      if (wide) {
+        if (P.compact == 2) {
+          if (stats) RT_LAUNCH_PERSIST(true, LT_WIDE | LT_NOPRIO | LT_COMPACT2);
+          else RT_LAUNCH_PERSIST(false, LT_WIDE | LT_NOPRIO | LT_COMPACT2);
+        } else if (P.compact) {
+          if (stats) RT_LAUNCH_PERSIST(true, LT_WIDE | LT_NOPRIO | LT_COMPACT);
+          else RT_LAUNCH_PERSIST(false, LT_WIDE | LT_NOPRIO | LT_COMPACT);
+        } else {
+          if (stats) RT_LAUNCH_PERSIST(true, LT_WIDE | LT_NOPRIO);
+          else RT_LAUNCH_PERSIST(false, LT_WIDE | LT_NOPRIO);
+        }
+      } else if (P.compact == 2) {
         if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT2);
         else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT2);
       } else if (P.compact) {
@@ -1752,6 +1833,9 @@ hipError_t launch_trace(bool brute_force, bool any, const DevScene& S, const rt_
   if (brute_force) {
     if (any) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, S, rays, n, hits, counters);
     else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, stream, S, rays, n, hits, counters);
+  } else if (S.nodes4) {  // the context traverses the wide form of its tree
+    if (any) hipLaunchKernelGGL((k_trace<false, true, LT_WIDE>), grid, block, 0, stream, S, rays, n, hits, counters);
+    else hipLaunchKernelGGL((k_trace<false, false, LT_WIDE>), grid, block, 0, stream, S, rays, n, hits, counters);
   } else {
     if (any) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, stream, S, rays, n, hits, counters);
     else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, stream, S, rays, n, hits, counters);

@@ -1,0 +1,41 @@
+"""The 4-wide form of the host-built BVH (csrc/bvh_build.cpp collapse4), checked without a GPU:
+rt_bvh_wide_check_host builds, collapses and verifies the structure itself (every triangle record
+reachable exactly once, every stored f16 child box containing its padded geometry, unused slots
+inert, the traversal-stack need as reported and within the budget)."""
+import pytest
+
+import pyrt
+
+
+@pytest.mark.parametrize("kind", ["cubes", "lowres", "hires"])
+@pytest.mark.parametrize("budget", [0, 20, 30])
+def test_wide_collapse_is_a_valid_tree(kind, budget):
+    s = pyrt.Scene(kind, 32, 32)
+    r = pyrt.bvh_wide_check_host(s, 0, budget)
+    assert r["binary_nodes"] == r["k2"] + 2 * r["k3"] + 3 * r["k4"]  # a wide node with k children replaces k - 1 binary ones
+    assert r["wide_nodes"] == r["k2"] + r["k3"] + r["k4"] < r["binary_nodes"]
+    assert r["binary_depth"] <= r["stack_need"] <= max(budget, r["binary_depth"])
+    assert r["visits4"] < r["visits2"]  # surface-area estimate of node visits per random ray
+
+
+def test_wide_collapse_respects_a_tight_stack_budget_and_uses_a_loose_one():
+    s = pyrt.Scene("hires", 32, 32)
+    tight, loose = pyrt.bvh_wide_check_host(s, 0, 0), pyrt.bvh_wide_check_host(s, 0, 30)
+    assert tight["stack_need"] == tight["binary_depth"]
+    assert loose["wide_nodes"] < tight["wide_nodes"] and loose["visits4"] < tight["visits4"]
+    assert loose["stack_need"] <= 30
+
+
+def test_wide_collapse_leaf_sizes_and_tiny_scenes():
+    for leaf in (1, 2, 4, 8):
+        r = pyrt.bvh_wide_check_host(pyrt.Scene("lowres", 32, 32), leaf, 0)
+        assert r["wide_nodes"] >= 1
+    # a scene of one and of two triangles: the root still has two (leaf) children
+    import numpy as np
+    a = pyrt.Scene("cubes", 32, 32).arrays()
+    for ntri in (1, 2, 3):
+        tri = a["tri"][:ntri]
+        sc = pyrt.ArrayScene(a["pos"], a["nrm"], tri, np.array([0, ntri], np.uint32), np.array([0, len(a["pos"])], np.uint32),
+                             a["materials"][:1], a["lights"], a["camera"])
+        r = pyrt.bvh_wide_check_host(sc, 0, 0)
+        assert r["wide_nodes"] >= 1 and r["stack_need"] >= 1
