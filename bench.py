@@ -90,9 +90,10 @@ def is_timed_render_kernel(name):
     return False
 
 
-def pmc_measure(args):
-    """rocprofv3 --pmc child passes over ONE frame of the same workload (program after `--`
-    is python3 itself; --kernel-trace only).  Returns {counter: value per launch} or None."""
+def pmc_measure(args, rank=0, world=1):
+    """rocprofv3 --pmc child passes over ONE frame of the same workload — at N > 1 over rank `rank`'s
+    SHARD of it, on device 0 of this process's view — (program after `--` is python3 itself;
+    --kernel-trace only).  Returns {counter: value per launch} or None."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
@@ -107,7 +108,8 @@ def pmc_measure(args):
             if args.spp:
                 cmd += ["--spp", str(args.spp)]
             # the child must run THIS run's kernel configuration (integrator, samples per wave, leaf size)
-            cmd += ["--integrator", args.integrator, "--lpp", str(args.lpp), "--leaf", str(args.leaf)]
+            cmd += ["--integrator", args.integrator, "--lpp", str(args.lpp), "--leaf", str(args.leaf),
+                    "--pmc-rank", str(rank), "--pmc-world", str(world)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             rows = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -122,7 +124,8 @@ def pmc_measure(args):
         return None, "%s: %s" % (type(e).__name__, e)
     finally:
         shutil.rmtree(base, ignore_errors=True)
-    return out, "rocprofv3 --pmc child passes of this run (1 frame each)"
+    return out, "rocprofv3 --pmc child passes of this run (1 frame each%s)" % (
+        "" if world == 1 else "; rank %d's shard of %d" % (rank, world))
 
 
 def pmc_child(args):
@@ -133,7 +136,7 @@ def pmc_child(args):
     spp = args.spp or spp
     scene = pyrt.Scene(kind, w, h)
     ctx = pyrt.Context(scene, device=0, bvh_leaf_max=args.leaf)
-    params = build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, 0, 1)
+    params = build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, args.pmc_rank, args.pmc_world)
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
     ctx.render_device(params, accum.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -141,7 +144,7 @@ def pmc_child(args):
 
 
 # ----------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(ctx, scene_kind, mode, device):
+def cpu_baseline(ctx, scene_kind, mode, device, full=False):
     """The REAL reference (oracle/_ref/ref_harness = reference sources + our driver), timed
     single-threaded on a bounded sample of the same scene and mode (96x96, 8 spp, ~10 s:
     brute force costs ~0.13 ms per sample on the low-res scene; BASELINE config 1 is the same
@@ -204,6 +207,18 @@ def cpu_baseline(ctx, scene_kind, mode, device):
                                    cwd=tmp, capture_output=True, text=True, check=True, timeout=300)
             secs = json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
             out.update({"value": rays / secs / 1e6, "kind": "reference", "seconds": secs})
+            if full:
+                # BASELINE.json configs[0] exactly: 256x256, -m 1 -N 8 on this scene (same code, 7x the work)
+                pf = pyrt.make_params(256, 256, 8, mode=mode, rng_mode=pyrt.RNG_LEGACY)
+                _, _, sf = orc.render(pyrt.Scene(scene_kind, 256, 256), pf, math_mode=orc.MATH_LIBM, accel=orc.ACCEL_OBVH)
+                with tempfile.TemporaryDirectory() as tmp:
+                    r = subprocess.run([harness, "time", pyrt.MESH_DIR, scene_kind, "256", "256", str(mode), "8", "0", "0"],
+                                       cwd=tmp, capture_output=True, text=True, check=True, timeout=900)
+                fsecs = json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
+                frays = sf.rays_closest + sf.rays_shadow
+                out.update({"full_config1_value": frays / fsecs / 1e6, "full_config1_seconds": fsecs, "full_config1_rays": frays,
+                            "full_config1_sample": "%s scene, 256x256, -m %d -N 8, legacy RNG seed 1: BASELINE.json configs[0] at "
+                                                   "its stated size, reference code, 1 thread" % (scene_kind, mode)})
             return out
         except Exception as e:  # the baseline must never cost the bench line: fall back to the port
             out["sample"] += " [reference harness failed: %s]" % type(e).__name__
@@ -228,8 +243,12 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="also time the reference's code on BASELINE config 1 at its stated size (256x256, -m 1 -N 8: ~70 s)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-world", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--accel", default="bvh", choices=["bvh", "brute"])
     ap.add_argument("--leaf", type=int, default=0, help="BVH leaf size override (debug)")
     ap.add_argument("--lpp", type=int, default=0, help="samples of a pixel per wave override (debug)")
@@ -250,12 +269,13 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank_env = int(os.environ.get("RANK", "0"))
     # counters of the timed kernel, measured now, by child processes, before this process
-    # initialises the GPU (N = 1 only: the counters describe one GPU's launch)
-    pmc, pmc_source = None, "skipped (--no-pmc)" if args.no_pmc else "not measured at N > 1"
+    # initialises the GPU.  At N > 1 rank 0 measures ITS shard (the counters describe one rank's
+    # launch; the others wait for it in the rendezvous), so the line carries a per-rank roofline.
+    pmc, pmc_source = None, "skipped (--no-pmc)" if args.no_pmc else "measured by rank 0 only"
     if args.integrator != "fused":
         pmc_source = "skipped: the counters are defined for the fused kernel (the wavefront integrator is several kernels)"
-    elif world_env == 1 and not args.no_pmc:
-        pmc, pmc_source = pmc_measure(args)
+    elif rank_env == 0 and not args.no_pmc:
+        pmc, pmc_source = pmc_measure(args, 0, world_env)
 
     import torch
     import pyrt
@@ -284,10 +304,19 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     frame = rdist.FrameAssembler(ctx, params, rank, world, dev)  # owned tiles -> rank 0 (one gather)
 
-    def step():
+    asm_events = []  # (before, after) the frame assembly on this rank's stream, timed steps only
+
+    def step(timed=False):
         accum.zero_()
         ctx.render_device(params, accum.data_ptr(), stream)
-        frame.assemble(accum, stream)
+        if timed and world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            frame.assemble(accum, stream)
+            e1.record()
+            asm_events.append((e0, e1))
+        else:
+            frame.assemble(accum, stream)
         if rank == 0:
             ctx.resolve_device(w, h, spp, accum.data_ptr(), bg.data_ptr(), out.data_ptr(), stream)
 
@@ -309,7 +338,7 @@ def main():
     ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     torch.cuda.synchronize()
     rdist.barrier()
     elapsed = time.perf_counter() - t0
@@ -317,6 +346,15 @@ def main():
     kernel_ms, launches = ctx.profile_collect()
     avg_ms = kernel_ms / max(launches, 1)
     secs = avg_ms * 1e-3
+    # per-rank kernel time (slowest / fastest rank: the load balance of the tile sharding) and the
+    # time rank 0's stream spends in the assembly (pack + gather + scatter; it includes waiting for
+    # the slowest rank's granules, i.e. skew + exchange)
+    kernel_ms_max = rdist.max_over_ranks(avg_ms, dev)
+    kernel_ms_min = -rdist.max_over_ranks(-avg_ms, dev)
+    assemble_ms = (sum(a.elapsed_time(b) for a, b in asm_events) / len(asm_events)) if asm_events else 0.0
+    exchange = ("none (one rank)" if world == 1 else
+                "%s gather of owned 8x8-pixel granules to rank 0 (%.2f MiB per rank and frame)" % (
+                    backend, max(frame.counts) * 64 * 16 / 2**20))
 
     # ALGORITHMIC bytes per launch (SURVEY §8d per-unit figures x the units of this launch): 32 B
     # per node record fetched (the packed node this build traverses; §8d priced a 64-B float
@@ -345,6 +383,8 @@ def main():
             # active lanes per VALU wave-instruction / 64
             lane_util = min(pmc["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 1.0)
 
+    if rank != 0:
+        rdist.shutdown()  # (before rank 0 starts its CPU baseline: nobody waits on anybody after this)
     if rank == 0:
         hbm_roof = {"bound": "hbm", "achieved": (hbm_bytes / secs / 1e9) if hbm_bytes and secs > 0 else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s"}
@@ -357,6 +397,7 @@ def main():
         roof.update({
             "traffic": hbm_bytes,  # measured HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)
             "traffic_source": pmc_source, "kernel_source_hash": khash,
+            "scope": "one launch of rank 0's shard (1/%d of the pixels)" % world if world > 1 else "one launch (whole frame)",
             "kernel": "k_render_persist" if args.accel == "bvh" and not nph else "k_render",
             "kernel_ms_avg": avg_ms, "launches": launches,
             "valu_issue": valu_roof, "hbm": hbm_roof,
@@ -392,12 +433,16 @@ def main():
                                    % (args.workload, kind, scene.desc.n_triangles, w, h, mode, spp,
                                       args.accel + (", wavefront integrator" if args.integrator == "wavefront" else "")),
                        "parallelism": "tiles32x%d, owned tiles gathered to rank 0" % world,
+                       "exchange": exchange, "assemble_ms": assemble_ms,
+                       "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_ms_min_over_ranks": kernel_ms_min,
                        "rays_per_frame": rays_per_frame, "samples_per_frame": tot[4],
                        "knn_queries_per_frame": tot[5]},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(ctx, kind, mode, dev)
+        if not args.no_cpu_baseline:
+            # (rank 0 only, after the timed region; at N > 1 the other ranks have left the job by now)
+            rdist.shutdown()
+            cb = cpu_baseline(ctx, kind, mode, dev, full=args.cpu_baseline_full)
             gpu_bvh = res["value"]
             cb["decomposition"] = {
                 "gpu_bvh_over_reference_1thread": gpu_bvh / cb["value"],

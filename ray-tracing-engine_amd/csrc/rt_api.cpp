@@ -1150,6 +1150,8 @@ struct rt_group {
   std::vector<rt_ctx*> ctx;
   std::vector<int> dev;
   std::vector<hipStream_t> stream;
+  hipStream_t xstream = nullptr;  // device 0: receives and scatters the other ranks' granules beside rank 0's own render
+  hipEvent_t assembled = nullptr; // ... and tells stream[0] when the frame is whole
   std::vector<hipEvent_t> packed_ready;
   std::vector<float4*> accum;   // [rank] full frame on that rank's device
   std::vector<float4*> packed;  // [rank] owned granules, on that rank's device (rank > 0)
@@ -1220,6 +1222,12 @@ int rt_group_create(const rt_scene_desc* scene, const int32_t* devices, uint32_t
     }
     g->ctx.push_back(c), g->dev.push_back(devices[r]), g->stream.push_back(s), g->packed_ready.push_back(e);
   }
+  (void)hipSetDevice(g->dev[0]);
+  if (hipStreamCreateWithFlags(&g->xstream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&g->assembled, hipEventDisableTiming) != hipSuccess) {
+    rt_group_destroy(g);
+    return fail(RT_ERR_HIP, "exchange stream creation failed on device %d", devices[0]);
+  }
   // exchange path: RCCL send/recv when every rank has its own device (ncclCommInitAll refuses
   // duplicates); ranks sharing a device (rehearsal on one GPU) use peer copies
   if (((n > 1 && distinct) || (n == 1 && getenv("RT_GROUP_FORCE_RCCL"))) && !getenv("RT_GROUP_NO_RCCL")) {
@@ -1245,6 +1253,9 @@ void rt_group_destroy(rt_group* g) {
   if (!g->ctx.empty()) group_free_frame(g);
   for (ncclComm_t c : g->comm)
     if (c) (void)g_rccl.CommDestroy(c);
+  if (!g->dev.empty()) (void)hipSetDevice(g->dev[0]);
+  if (g->xstream) (void)hipStreamDestroy(g->xstream);
+  if (g->assembled) (void)hipEventDestroy(g->assembled);
   for (size_t r = 0; r < g->ctx.size(); ++r) {
     (void)hipSetDevice(g->dev[r]);
     if (g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
@@ -1299,6 +1310,10 @@ int rt_group_render(rt_group* g, const rt_params* p, const float* bg, float* out
     pr.rank = r;
     HIP_TRY(hipSetDevice(g->dev[r]));
     HIP_TRY(hipMemsetAsync(g->accum[r], 0, npx * sizeof(float4), g->stream[r]));
+    if (r == 0) {  // the exchange stream scatters into this buffer: only after it has been zeroed
+      HIP_TRY(hipEventRecord(g->assembled, g->stream[0]));
+      HIP_TRY(hipStreamWaitEvent(g->xstream, g->assembled, 0));
+    }
     HIP_TRY(hipMemsetAsync(g->ctx[r]->dCounters, 0, RTK_CNT_COUNT * sizeof(unsigned long long), g->stream[r]));
     rc = launch_frame(g->ctx[r], &pr, g->accum[r], g->stream[r], &ev[r]);
     if (rc != RT_OK) return rc;
@@ -1308,14 +1323,16 @@ int rt_group_render(rt_group* g, const rt_params* p, const float* bg, float* out
       HIP_TRY(hipEventRecord(g->packed_ready[r], g->stream[r]));
     }
   }
-  // 2. owned granules travel to rank 0's device: 1/N of the frame per rank, nothing else
+  // 2. owned granules travel to rank 0's device: 1/N of the frame per rank, nothing else.  Device 0
+  // receives and scatters them on its EXCHANGE stream, beside its own render on stream[0] (the
+  // pixels are disjoint), so a rank that finishes early is assembled while the others still render.
   if (g->rccl) {
     ncclResult_t nr = g_rccl.GroupStart();
     for (uint32_t r = 1; r < n && nr == ncclSuccess; ++r) {
       if (!cnt[r]) continue;
       const size_t floats = (size_t)cnt[r] * 64 * 4;
       nr = g_rccl.Send(g->packed[r], floats, ncclFloat, 0, g->comm[r], g->stream[r]);
-      if (nr == ncclSuccess) nr = g_rccl.Recv(g->recv[r], floats, ncclFloat, static_cast<int>(r), g->comm[0], g->stream[0]);
+      if (nr == ncclSuccess) nr = g_rccl.Recv(g->recv[r], floats, ncclFloat, static_cast<int>(r), g->comm[0], g->xstream);
     }
     const ncclResult_t ne = g_rccl.GroupEnd();
     if (nr == ncclSuccess) nr = ne;
@@ -1324,17 +1341,19 @@ int rt_group_render(rt_group* g, const rt_params* p, const float* bg, float* out
     HIP_TRY(hipSetDevice(g->dev[0]));
     for (uint32_t r = 1; r < n; ++r) {
       if (!cnt[r]) continue;
-      HIP_TRY(hipStreamWaitEvent(g->stream[0], g->packed_ready[r], 0));
-      HIP_TRY(hipMemcpyPeerAsync(g->recv[r], g->dev[0], g->packed[r], g->dev[r], (size_t)cnt[r] * 64 * sizeof(float4), g->stream[0]));
+      HIP_TRY(hipStreamWaitEvent(g->xstream, g->packed_ready[r], 0));
+      HIP_TRY(hipMemcpyPeerAsync(g->recv[r], g->dev[0], g->packed[r], g->dev[r], (size_t)cnt[r] * 64 * sizeof(float4), g->xstream));
     }
   }
   // 3. rank 0 scatters them into its frame, resolves (Renderer.cpp:262-265) and hands the image back
   HIP_TRY(hipSetDevice(g->dev[0]));
   for (uint32_t r = 1; r < n; ++r) {
     if (!cnt[r]) continue;
-    rc = rt_unpack_owned_device(g->ctx[0], &base, r, g->recv[r], g->accum[0], g->stream[0]);
+    rc = rt_unpack_owned_device(g->ctx[0], &base, r, g->recv[r], g->accum[0], g->xstream);
     if (rc != RT_OK) return rc;
   }
+  HIP_TRY(hipEventRecord(g->assembled, g->xstream));
+  HIP_TRY(hipStreamWaitEvent(g->stream[0], g->assembled, 0));
   hipError_t he = hipSuccess;
   if (out_rgb) {
     he = hipMemcpyAsync(g->dBg, bg, npx * 3 * sizeof(float), hipMemcpyHostToDevice, g->stream[0]);
@@ -1348,6 +1367,8 @@ int rt_group_render(rt_group* g, const rt_params* p, const float* bg, float* out
     HIP_TRY(hipSetDevice(g->dev[r]));
     HIP_TRY(hipStreamSynchronize(g->stream[r]));
   }
+  HIP_TRY(hipSetDevice(g->dev[0]));
+  HIP_TRY(hipStreamSynchronize(g->xstream));
   if (stats) {
     memset(stats, 0, sizeof *stats);
     for (uint32_t r = 0; r < n; ++r) {

@@ -111,13 +111,21 @@ def test_bench_spawns_its_own_launcher(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(RT_DIST_BACKEND="gloo", RT_SHARE_GPU="1", MASTER_PORT="29733")
     r = subprocess.run([sys.executable, os.path.join(pyrt.ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
-                        "--workload", "C1"], capture_output=True, text=True, env=env, timeout=300, cwd=tmp_path)
+                        "--workload", "C1"], capture_output=True, text=True, env=env, timeout=900, cwd=tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["config"]["rays_per_frame"] == 5526901 and d["value"] > 0
     assert "owned tiles gathered" in d["config"]["parallelism"]
+    # the N > 1 line is complete and attributable — a per-rank roofline measured by
+    # rank 0's own PMC child passes on its shard, the CPU baseline, and where the frame time goes
+    roof, cfg = d["roofline"], d["config"]
+    assert roof["frac"] is not None and 0 < roof["frac"] <= 1 and "rank 0's shard of 3" in roof["traffic_source"]
+    assert roof["valu_issue"]["frac"] is not None and roof["traffic"] is not None and "1/3" in roof["scope"]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
+    assert cfg["assemble_ms"] > 0 and cfg["kernel_ms_max_over_ranks"] >= cfg["kernel_ms_min_over_ranks"] > 0
+    assert "gather of owned 8x8-pixel granules" in cfg["exchange"]
 
 
 def test_progressive_update_ppm_matches_the_reference_semantics(tmp_path):
