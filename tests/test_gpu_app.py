@@ -87,13 +87,14 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29711", os.path.join(pyrt.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--workload", "C1"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=tmp_path)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
     two = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     r1 = subprocess.run([sys.executable, os.path.join(pyrt.ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "C1",
                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
     one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
-    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "cpu_baseline" not in two
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["cpu_baseline"]["value"] > 0  # (rank 0 times the CPU beside it at every N)
     assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"] == 5526901
     for k in ("metric", "value", "unit", "ms_per_step", "roofline", "dtype", "data", "vs_baseline", "higher_is_better"):
         assert k in two and k in one
