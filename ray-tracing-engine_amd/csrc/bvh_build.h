@@ -77,10 +77,13 @@ constexpr int kMaxDepth = 32;      // traversal stack entries per lane
 // LDS budget of the pooled render kernel (rt_kernels.hip plan_persist), which the depth cap is chosen
 // against: words per CU available to the waves, words of a wave's ray pool, words per stack row
 // (the diagnostic RT_PHASE_TIMING build keeps 256 B of static LDS; the product build has none)
+// (kCtlWords: the persistent workgroup's control block — pool descriptors and the availability mask of
+// the CU-level ray sharing, rt_kernels.hip vertex_pool_cus — sits behind the waves' regions)
+constexpr uint32_t kCtlWords = 80u;
 #ifdef RT_PHASE_TIMING
-constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - 64u;
+constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - 64u - kCtlWords;
 #else
-constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u;
+constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - kCtlWords;
 #endif
 constexpr uint32_t kWavePoolWords = 1128u, kStackRowWords = 64u;
 // waves (of at most 16) that fit a CU beside their stacks for a tree of this depth (+1: the sentinel row)

@@ -62,7 +62,7 @@ __shared__ unsigned long long g_phT0;
 #define PHC(p) do { } while (0)
 #endif
 enum { PH_SETUP = 0, PH_PRIMARY, PH_VSETUP, PH_FILL, PH_HANDOUT, PH_STEAL, PH_DESCENT, PH_LEAF, PH_POOLMISC, PH_BSDF,
-       PH_ACCUM, PH_N_ROUNDS, PH_N_STEPS, PH_N_POOLS, PH_TAIL, PH_COUNT };
+       PH_ACCUM, PH_N_ROUNDS, PH_N_STEPS, PH_N_POOLS, PH_TAIL, PH_FOREIGN, PH_COUNT };
 
 struct LaneStats {
   uint32_t closest = 0, shadow = 0, knn = 0, nodes = 0, tris = 0, kd = 0;
@@ -190,6 +190,9 @@ constexpr int LT_COMPACT2 = 32;
 // sorted by entry distance, the nearest is entered, the others pushed far to near.  Half the DEPENDENT
 // fetches per ray: the lever on scenes whose nodes come from L2 / HBM.
 constexpr int LT_WIDE = 64;
+// CU-level ray sharing (vertex_pool_cus): a wave whose own pool has no rays left to hand out takes
+// fresh rays from the pools of the other waves of its workgroup instead of idling through its tail.
+constexpr int LT_CUS = 128;
 constexpr uint32_t kPrioMaxNodes = 65536;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
@@ -492,12 +495,12 @@ struct Trav {
   // pool mode: make this lane's closest hit visible to the other lanes / the pixel lane
   RT_DEV void publish() {
     const unsigned long long key = ((unsigned long long)__float_as_uint(hit.t) << 32) | hit.id;
-    atomicMin(sharedKey + pj, key);
+    atomicMin(sharedKey + (int32_t)pj, key);
   }
 
   // pool mode: adopt a closer hit another lane has published for the same ray
   RT_DEV void refresh_best() {
-    const unsigned long long key = sharedKey[pj];
+    const unsigned long long key = sharedKey[(int32_t)pj];
     const float kt = __uint_as_float((uint32_t)(key >> 32));
     const uint32_t kid = (uint32_t)key;
     if (key != ~0ull && (kt < best || (kt == best && kid < bestId))) best = kt, bestId = kid;
@@ -1059,6 +1062,307 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   return color;
 }
 
+// ---------------------------------------------------------------- vertex pool with CU-level ray sharing
+// The 16 waves of a persistent workgroup run their pools at different phases: while one wave is in
+// its tail (its last long rays on a handful of lanes, nothing left to hand out) others still have
+// more rays than lanes.  Here a wave in that state takes FRESH rays from another wave's pool: every
+// pool has a descriptor in the workgroup's control block —
+//   [0] claim word   generation << 16 | next rank to hand out   (owner: atomic add; others: CAS on
+//                    the word they validated, so a claim can never land in a later generation)
+//   [1] info         R | n << 9 | n_lights << 16 | bounce << 18
+//   [2] fdone        rays finished by OTHER waves' lanes (their results are already in the pool)
+// — and the control block's word 0 is the mask of pools that still have unclaimed rays.  A foreign
+// lane reads the ray from the owner's pool, walks it, writes the result where the owner's own lanes
+// would (the occlusion bit by atomic or, the bounce key by atomic min) and counts it in fdone; the
+// owner leaves its pool loop when its own lanes are done AND fdone equals the rays it did not claim
+// itself.  Rays taken by another wave are walked by exactly one lane (in-wave stealing only splits
+// a wave's own rays), so "finished" is well defined.  Everything is LDS traffic between waves of one
+// CU: per-wave DS order + workgroup-scope fences, no barrier.  Results are bit-identical: who walks a
+// ray never mattered.
+constexpr int CU_AVAIL = 0, CU_DESC = 4, CU_DESC_WORDS = 4;
+static_assert(CU_DESC + 16 * CU_DESC_WORDS <= (int)rtbvh::kCtlWords, "control block");
+
+RT_DEV uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <bool STATS, int LT>
+RT_DEV f3 vertex_pool_cus(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
+                          f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
+                          uint32_t* ctl, uint32_t wv, int32_t waveWords, uint32_t& gen) {
+  static_assert(!(LT & (LT_COMPACT2 | LT_SS | LT_WIDE)), "CU sharing: full or light-parameter pools, plain stack, binary nodes");
+  const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
+  constexpr bool CP = (LT & LT_COMPACT) != 0;
+  using VP = VpLayout<CP ? 1 : 0>;
+  float* fp = reinterpret_cast<float*>(pool);
+  uint32_t* list = pool + VP::LIST;
+  uint8_t* listB = reinterpret_cast<uint8_t*>(list);
+  uint32_t* res = pool + VP::RES;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(pool + VP::KEY);
+  const uint64_t amask = wave_ballot(alive);
+  const uint32_t n = (uint32_t)__popcll(amask);
+  f3 color = mk(0.f, 0.f, 0.f);
+  nextFound = false;
+  if (n == 0) return color;
+  PH(PH_VSETUP);
+  PHC(PH_N_POOLS);
+  if (alive) {
+    fp[VP_PT + lane] = point.x, fp[VP_PT + 64 + lane] = point.y, fp[VP_PT + 128 + lane] = point.z;
+    for (uint32_t l = 0; l < nl; l++) {
+      if (CP) {
+        float rh, rv;
+        light_sample_params(g, S.lights[l], rh, rv);
+        fp[VP_DIR + (2 * l + 0) * 64 + lane] = rh, fp[VP_DIR + (2 * l + 1) * 64 + lane] = rv;
+      } else {
+        const f3 tl = light_sample(g, S.lights[l]) - point;
+        fp[VP_DIR + (3 * l + 0) * 64 + lane] = tl.x, fp[VP_DIR + (3 * l + 1) * 64 + lane] = tl.y, fp[VP_DIR + (3 * l + 2) * 64 + lane] = tl.z;
+      }
+    }
+    if (bounce) {
+      const f3 bd = hemisphere_sample(g, hitNormal);
+      fp[VP::BDIR + lane] = bd.x, fp[VP::BDIR + 64 + lane] = bd.y, fp[VP::BDIR + 128 + lane] = bd.z;
+      keys[lane] = ~0ull;
+    }
+    listB[lanes_below(amask)] = (uint8_t)lane;
+    st.shadow += nl;
+    if (bounce) st.closest++;
+  }
+  if (lane < 2 * POOL_L) res[lane] = 0;
+  const uint32_t kinds = nl + (bounce ? 1u : 0u), R = n * kinds;
+  const uint32_t first = R < 64u ? R : 64u;  // the first hand-out: ranks [0, first) go to this wave's own lanes
+  uint32_t* const D = ctl + CU_DESC + wv * CU_DESC_WORDS;
+  gen = (gen + 1u) & 0x7fffu;
+  // the pool first, then its descriptor, the claim word last, then the mask bit (per-wave DS order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    __hip_atomic_store(&D[1], R | (n << 9) | (nl << 16) | (bounce ? 1u << 18 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&D[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&D[0], (gen << 16) | first, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (first < R) __hip_atomic_fetch_or(&ctl[CU_AVAIL], 1u << wv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  wave_sync();
+  PH(PH_FILL);
+  uint32_t ownClaimed = first;
+  bool exhausted = first >= R;
+  uint32_t kjw = 0;  // kind | pixel lane << 8 | owner wave << 16 of the ray this lane walks
+  Trav<TRAV_MIXED, LT> T;
+  T.idle(stack, nullptr, 0);
+  T.sharedKey = keys, T.pj = 0;
+  uint32_t* stackBase = stack - lane;
+  bool firstRound = true;
+  bool foreignOpen = false;  // another pool of the workgroup still has rays to hand out (as of the last look)
+  if (!(LT & LT_NOPRIO)) __builtin_amdgcn_s_setprio(1);
+  for (;;) {
+    const uint64_t idle = wave_ballot(!T.live());
+    const int nIdle = __popcll(idle);
+    bool newRay = false, newShared = false;
+    uint32_t newK = 0, newJ = 0, newW = wv;
+    int32_t newNode = 0;
+    if (firstRound) {
+      // every lane is free: rank = lane
+      firstRound = false;
+      if (lane < first) {
+        uint32_t k = (lane >= n) + (lane >= 2 * n) + (lane >= 3 * n);
+        const uint32_t j = listB[lane - k * n];
+        k = bounce ? (k == 0 ? nl : k - 1) : k;  // (the bounce rays, the longest walks, first)
+        newRay = true, newK = k, newJ = j;
+      }
+      PH(PH_HANDOUT);
+    } else if (!exhausted) {
+      if (nIdle >= (int)S.refillT || nIdle == 64) {
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&D[0], (uint32_t)nIdle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old) & 0xffffu;
+        const uint32_t r = old + lanes_below(idle);
+        if (!T.live() && r < R) {
+          uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);
+          const uint32_t j = listB[r - k * n];
+          k = bounce ? (k == 0 ? nl : k - 1) : k;
+          newRay = true, newK = k, newJ = j;
+        }
+        const uint32_t hi = old + (uint32_t)nIdle;
+        ownClaimed += (hi < R ? hi : R) - (old < R ? old : R);
+        if (hi >= R) {
+          exhausted = true;
+          if (lane == 0) __hip_atomic_fetch_and(&ctl[CU_AVAIL], ~(1u << wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      PH(PH_HANDOUT);
+    } else {
+      // This pool has nothing left to hand out.  While ANY pool of the workgroup still has, the wave goes
+      // on as in its own hand-out phase — free lanes (>= refillT of them) take fresh rays there —; only
+      // when every pool is drained does it split its own last long rays (in-wave stealing, >= stealT).
+      const bool own = (kjw >> 16) == wv;
+      uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(&ctl[CU_AVAIL])) & ~(1u << wv);
+      if (mask) {
+        // (a wave whose own pool is complete only finishes what it holds and moves on)
+        const bool ownLive = wave_ballot(T.live() && own) != 0;
+        if (!ownLive && lds_load(&D[2]) == R - ownClaimed) mask = 0, foreignOpen = false;
+      }
+      foreignOpen = mask != 0;
+      if (mask) {
+        if (nIdle >= (int)S.refillT || nIdle == 64) {
+          // the next pool after this wave's own, cyclically (waves spread over the victims)
+          const uint32_t rot = (mask >> (wv + 1u)) | (mask << (31u - wv));  // bit b of rot <-> wave (wv + 1 + b) mod 32; waves < 16
+          const uint32_t v = (wv + 1u + (uint32_t)__builtin_ctz(rot)) & 31u;
+          uint32_t* const DV = ctl + CU_DESC + v * CU_DESC_WORDS;
+          const uint32_t hw = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&DV[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+          const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(&DV[1]));
+          const uint32_t Rv = info & 511u, nv = (info >> 9) & 127u, nlv = (info >> 16) & 3u, bv = (info >> 18) & 1u;
+          const uint32_t hv = hw & 0xffffu;
+          if (hv < Rv) {
+            const uint32_t take = (uint32_t)nIdle < Rv - hv ? (uint32_t)nIdle : Rv - hv;
+            uint32_t seen = ~hw;
+            if (lane == 0) {
+              seen = hw;
+              __hip_atomic_compare_exchange_strong(&DV[0], &seen, hw + take, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
+            if (seen == hw) {  // ranks [hv, hv + take) of pool v, generation hw >> 16, are this wave's
+              const uint32_t r = hv + lanes_below(idle);
+              if (!T.live() && r < hv + take) {
+                const uint8_t* listV = listB + (int32_t)(v - wv) * waveWords * 4;
+                uint32_t k = (r >= nv) + (r >= 2 * nv) + (r >= 3 * nv);
+                const uint32_t j = listV[r - k * nv];
+                k = bv ? (k == 0 ? nlv : k - 1) : k;
+                newRay = true, newK = k, newJ = j, newW = v;
+              }
+              if (hv + take >= Rv && lane == 0) __hip_atomic_fetch_and(&ctl[CU_AVAIL], ~(1u << v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          } else if (lane == 0) {
+            __hip_atomic_fetch_and(&ctl[CU_AVAIL], ~(1u << v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a stale bit)
+          }
+        }
+        PH(PH_FOREIGN);
+      } else if (nIdle >= (int)S.stealT) {
+        // split this wave's own long rays (as vertex_pool does; only lanes that walk a ray of THIS pool give:
+        // a ray taken from another wave is walked by exactly one lane, so that "finished" is well defined)
+        uint16_t* list16 = reinterpret_cast<uint16_t*>(list);
+        uint32_t given = 0;
+        const int avail = (T.live() && own) ? T.depth() - T.stolen : 0;
+        int gave = 0;
+        for (int pass = 0; pass < 4; pass++) {
+          const bool canGive = avail > pass;
+          const uint64_t vmask = wave_ballot(canGive);
+          if (vmask == 0 || given >= (uint32_t)nIdle) break;
+          const uint32_t slot = given + lanes_below(vmask);
+          const bool gives = canGive && slot < (uint32_t)nIdle;
+          if (gives) list16[slot] = (uint16_t)(lane | ((uint32_t)(T.stolen + pass) << 6));
+          gave += gives ? 1 : 0;
+          given += (uint32_t)__popcll(vmask);
+        }
+        if (gave) {
+          if (!T.shared && !T.anyHit && T.found) T.publish();
+          T.shared = true;
+          T.stolen += gave;
+        }
+        given = given < (uint32_t)nIdle ? given : (uint32_t)nIdle;
+        if (given != 0) {
+          wave_sync();
+          const uint32_t q = lanes_below(idle);
+          const bool thief = !T.live() && q < given;
+          const uint32_t w = thief ? (uint32_t)list16[q] : lane;
+          const uint32_t v = w & 63u, e = w >> 6;
+          const uint32_t kj = (uint32_t)__shfl((int)kjw, (int)v, 64);  // (all lanes take part)
+          if (thief) {
+            uint32_t* slot = stackBase + (e + 1u) * BLOCK + v;  // (row 0 is the sentinel)
+            newNode = (int32_t)*slot;
+            *slot = (uint32_t)TERM;
+            newRay = true, newShared = true, newK = kj & 255u, newJ = (kj >> 8) & 255u;
+          }
+          wave_sync();
+        }
+        PH(PH_STEAL);
+      }
+    }
+    if (newRay) {
+      const int32_t off = (int32_t)(newW - wv) * waveWords;  // the owner's pool, in words from this wave's
+      const float* fq = fp + off;
+      const f3 pj = mk(fq[VP_PT + newJ], fq[VP_PT + 64 + newJ], fq[VP_PT + 128 + newJ]);
+      f3 dj;
+      if (CP) {
+        if (newK < nl) {
+          const rt_light& Lt = S.lights[newK];
+          const float rh = fq[VP_DIR + (2 * newK + 0) * 64 + newJ], rv = fq[VP_DIR + (2 * newK + 1) * 64 + newJ];
+          dj = light_point(Lt, rh, rv) - pj;
+        } else {
+          dj = mk(fq[VP::BDIR + newJ], fq[VP::BDIR + 64 + newJ], fq[VP::BDIR + 128 + newJ]);
+        }
+      } else {
+        const uint32_t src = newK < nl ? VP_DIR + 192 * newK : VP::BDIR;
+        dj = mk(fq[src + newJ], fq[src + 64 + newJ], fq[src + 128 + newJ]);
+      }
+      T.start(pj, dj, S.invBoxScale);
+      if (T.live()) T.cur = newNode;  // (a NaN ray stays dead)
+      T.anyHit = newK < nl, T.shared = newShared;
+      T.pj = newJ + (uint32_t)(off / 2);  // (index into the OWNER's keys, counted from this wave's)
+      kjw = newK | (newJ << 8) | (newW << 16);
+      // a foreign ray that is dead on arrival is finished
+      if (!T.live() && newW != wv) __hip_atomic_fetch_add(ctl + CU_DESC + newW * CU_DESC_WORDS + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (wave_ballot(T.live()) == 0) {
+      // nothing to walk: done when nothing is left to claim and the others have returned their share
+      if (exhausted) {
+        if (lds_load(&D[2]) == R - ownClaimed) break;
+        __builtin_amdgcn_s_sleep(2);
+        PH(PH_FOREIGN);
+      }
+      continue;
+    }
+    const int need = min(64, (exhausted && !foreignOpen) ? (int)S.stealT : (int)S.refillT);
+    for (;;) {
+      const uint32_t myK = kjw & 255u, myJ = (kjw >> 8) & 255u;
+      if (T.shared && T.live()) {  // (shared rays are this pool's own)
+        if (T.anyHit) {
+          if ((res[myK * 2 + (myJ >> 5)] >> (myJ & 31)) & 1u) T.cur = TERM;
+        } else {
+          T.refresh_best();
+        }
+      }
+      const bool was = T.live();
+      PH(PH_POOLMISC);
+      if (exhausted && !foreignOpen) PHC(PH_TAIL);
+      T.template round<STATS>(S, st);
+      if (was && !T.live()) {
+        const uint32_t myW = kjw >> 16;
+        const int32_t off = (int32_t)(myW - wv) * waveWords;
+        if (T.found) {
+          if (myK < nl) atomicOr(res + off + (myK * 2 + (myJ >> 5)), 1u << (myJ & 31));
+          else if (!T.shared) T.publish();  // shared rays publish every improvement as it happens
+        }
+        if (myW != wv) __hip_atomic_fetch_add(ctl + CU_DESC + myW * CU_DESC_WORDS + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (__popcll(wave_ballot(!T.live())) >= need) break;
+    }
+  }
+  if (!(LT & LT_NOPRIO)) __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  wave_sync();
+  PH(PH_POOLMISC);
+  const f3 pt = mk(fp[VP_PT + lane], fp[VP_PT + 64 + lane], fp[VP_PT + 128 + lane]);
+  point = pt;
+  if (bounce) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
+  if (alive) {
+    const BsdfBase base = bsdf_base(S.mats[mesh], hitNormal, -rayDir);
+    for (uint32_t l = 0; l < nl; l++) {
+      if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
+      const f3 toLight = CP ? light_point(S.lights[l], fp[VP_DIR + (2 * l + 0) * 64 + lane], fp[VP_DIR + (2 * l + 1) * 64 + lane]) - pt
+                            : mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
+      const f3 bsdf = bsdf_apply(base, toLight);
+      const f3 radiance = light_eval(S.lights[l], pt);
+      color = color + radiance * bsdf;
+    }
+    if (bounce) {
+      const unsigned long long key = keys[lane];
+      nextFound = key != ~0ull;
+      next.t = __uint_as_float((uint32_t)(key >> 32)), next.id = (uint32_t)key;
+      next.u = next.v = 0.f, next.mesh = 0u;
+    }
+  }
+  wave_sync();
+  PH(PH_BSDF);
+  return color;
+}
+
 RT_DEV uint32_t wave_sum(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
@@ -1102,9 +1406,16 @@ RT_DEV Lds carve_lds(uint32_t* base, uint32_t levels = STACK, uint32_t kslots = 
 // direct-lighting step exchanges rays between lanes through LDS.
 // One wave tile: lane = (pixel pl of the tile, sample slot sj).  The wave integrates
 // S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side.
+struct CuShare {  // CU-level ray sharing (vertex_pool_cus): the workgroup's control block and this wave's place in it
+  uint32_t* ctl = nullptr;
+  uint32_t wv = 0;
+  int32_t waveWords = 0;
+  uint32_t gen = 0;
+};
+
 template <bool BRUTE, bool PHOTON, bool POOLED, bool STATS, int LT>
 RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restrict__ accum, const Lds& L, uint32_t* pool,
-                        float* ex, uint32_t wave, LaneStats& st) {
+                        float* ex, uint32_t wave, LaneStats& st, CuShare* cu = nullptr) {
   const uint32_t lane = threadIdx.x & 63u;
   // lane = (pixel pl of the wave tile, sample slot sj): the wave integrates
   // S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side
@@ -1133,7 +1444,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
       // primary ray (coherent: traced in lock step), then one pool per vertex
       HitRec h;
       if (alive) st.closest++;
-      const bool hit0 = cast<false, false, STATS, LT>(S, alive, o, d, L.stack, h, st, L.over);
+      const bool hit0 = cast<false, false, STATS, LT & ~LT_CUS>(S, alive, o, d, L.stack, h, st, L.over);
       if (alive && !hit0) primary = false, alive = false;
       for (int depth = 0; depth < nvert; depth++) {
         if (wave_ballot(alive) == 0) break;
@@ -1149,7 +1460,12 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
         // stream ends there — the pool only draws it when a bounce ray follows)
         HitRec nh;
         bool nfound;
-        const f3 c = vertex_pool<STATS, LT>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st, L.over);
+        f3 c;
+        if constexpr ((LT & LT_CUS) != 0)
+          c = vertex_pool_cus<STATS, LT & ~LT_CUS>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st, cu->ctl, cu->wv,
+                                                   cu->waveWords, cu->gen);
+        else
+          c = vertex_pool<STATS, LT>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st, L.over);
         if (alive) {
           if (depth == 0) c0 = c;
           else if (depth == 1) c1 = c;
@@ -1249,6 +1565,9 @@ __global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs 
     uint4* dst = reinterpret_cast<uint4*>(g_lds);
     for (uint32_t i = threadIdx.x; i < 2u * S.topK; i += blockDim.x) dst[i] = S.nodes[i];
   }
+  // the control block of the CU-level ray sharing: behind the waves' regions
+  uint32_t* const ctl = g_lds + 8u * S.topK + (blockDim.x >> 6) * A.waveWords;
+  if ((LT & LT_CUS) && threadIdx.x < rtbvh::kCtlWords) ctl[threadIdx.x] = 0u;
   __syncthreads();  // the only workgroup-wide barrier
   uint32_t* mine = g_lds + 8u * S.topK + wv * A.waveWords;
   Lds L = carve_lds<false>(mine, A.stackLevels, 0);
@@ -1256,6 +1575,8 @@ __global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs 
   uint32_t* pool = mine + A.stackLevels * BLOCK;
   float* ex = reinterpret_cast<float*>(pool);
   LaneStats st;
+  CuShare cu;
+  cu.ctl = ctl, cu.wv = wv, cu.waveWords = (int32_t)A.waveWords;
 #ifdef RT_PHASE_TIMING
   if (threadIdx.x < 24) g_phAcc[threadIdx.x] = 0;
   if (threadIdx.x == 0) g_phT0 = __builtin_amdgcn_s_memtime();
@@ -1266,7 +1587,7 @@ __global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs 
     if (lane == 0) t = atomicAdd(A.tileCounter, 1u);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     if (t >= A.n_tiles) break;
-    render_tile<false, false, true, STATS, LT>(S, A, accum, L, pool, ex, t, st);
+    render_tile<false, false, true, STATS, LT>(S, A, accum, L, pool, ex, t, st, &cu);
   }
 #ifdef RT_PHASE_TIMING
   __syncthreads();
@@ -1614,7 +1935,8 @@ static bool allow_big_lds(K kernel, unsigned long long& done) {
 #endif
   // (the diagnostic build stays 256 B short of the CU's 160 KiB for its static LDS: the attribute
   // is refused when static + dynamic exceed the CU)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * rtbvh::kLdsWordsPerCU);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             4 * (rtbvh::kLdsWordsPerCU + rtbvh::kCtlWords));
   done |= 1ull << dev;
   return true;
 }
@@ -1713,9 +2035,15 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   do {                                                                                                                  \
     static unsigned long long done = 0;                                                                                 \
     if (!allow_big_lds(&k_render_persist<ST, LTV>, done)) return hipErrorInvalidConfiguration;                          \
-    hipLaunchKernelGGL((k_render_persist<ST, LTV>), dim3(wgs), dim3(64u * P.waves), P.ldsBytes, stream, S2, A2, accum,  \
-                       counters);                                                                                       \
+    hipLaunchKernelGGL((k_render_persist<ST, LTV>), dim3(wgs), dim3(64u * P.waves), P.ldsBytes + 4u * rtbvh::kCtlWords, \
+                       stream, S2, A2, accum, counters);                                                                \
   } while (0)
+      // CU-level ray sharing (vertex_pool_cus): OPT-IN, RT_CUSHARE=1.  Built, bit-exact and measured:
+      // C2 66.2 vs 50.8 ms, lanes per node step 29.4 vs 36.4 — sharing balances the 16 pools of a CU, so they drain
+      // together and the tail becomes CU-wide; what bounds a pool is the dependency chain of its samples (one
+      // longest ray per path depth), not the spread between waves.
+      static const bool cuShare = getenv("RT_CUSHARE") && atoi(getenv("RT_CUSHARE")) != 0;
+      const bool cus = cuShare && P.waves > 1u;
       const int lt = P.topK == 0 ? LT_NONE : P.topK >= S.n_nodes ? LT_ALL : LT_TOP;
       if (wide) {
         if (P.compact == 2) {
@@ -1732,8 +2060,13 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
         if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT2);
         else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT2);
       } else if (P.compact) {
-        if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT);
-        else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT);
+        if (cus) {
+          if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT | LT_CUS);
+          else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT | LT_CUS);
+        } else {
+          if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT);
+          else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT);
+        }
       } else if (P.ssRows) {
         if (stats) {
           if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP | LT_SS);
@@ -1741,6 +2074,18 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
         } else {
           if (lt == LT_TOP) RT_LAUNCH_PERSIST(false, LT_TOP | LT_SS);
           else RT_LAUNCH_PERSIST(false, LT_NONE | LT_SS);
+        }
+      } else if (cus) {
+        if (stats) {
+          if (lt == LT_ALL) RT_LAUNCH_PERSIST(true, LT_ALL | LT_CUS);
+          else if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP | LT_CUS);
+          else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_CUS);
+          else RT_LAUNCH_PERSIST(true, LT_NONE | LT_CUS);
+        } else {
+          if (lt == LT_ALL) RT_LAUNCH_PERSIST(false, LT_ALL | LT_CUS);
+          else if (lt == LT_TOP) RT_LAUNCH_PERSIST(false, LT_TOP | LT_CUS);
+          else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_CUS);
+          else RT_LAUNCH_PERSIST(false, LT_NONE | LT_CUS);
         }
       } else if (stats) {
         if (lt == LT_ALL) RT_LAUNCH_PERSIST(true, LT_ALL);

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracing-engine_amd"))
 sys.path.insert(0, ROOT)
 NAMES = ["setup", "primary_misc", "vertex_setup", "pool_fill", "handout", "steal", "descent", "leaf", "pool_misc", "bsdf",
-         "accum", "n_rounds", "n_steps", "n_pools", "n_tail_rounds"]
+         "accum", "n_rounds", "n_steps", "n_pools", "n_tail_rounds", "foreign"]
 
 
 def main():
@@ -35,10 +35,10 @@ def main():
         lines = [l for l in tmp.read().decode().splitlines() if "phase_clocks" in l]
     clocks = json.loads(lines[-1])["phase_clocks"]
     d = dict(zip(NAMES, clocks))
-    tot = sum(clocks[:11])
+    tot = sum(clocks[:11]) + d.get("foreign", 0)
     rays = st.rays_closest + st.rays_shadow
     out = {"workload": wl, "spp": spp, "kernel_ms": st.kernel_ms, "rays": rays,
-           "share": {n: round(d[n] / tot, 4) for n in NAMES[:11]},
+           "share": {n: round(d[n] / tot, 4) for n in NAMES[:11] + ["foreign"]},
            "rounds_per_pool": d["n_rounds"] / max(d["n_pools"], 1), "steps_per_round": d["n_steps"] / max(d["n_rounds"], 1),
            "tail_round_frac": d["n_tail_rounds"] / max(d["n_rounds"], 1),
            "clocks_per_step_descent": d["descent"] / max(d["n_steps"], 1), "clocks_per_round_leaf": d["leaf"] / max(d["n_rounds"], 1),
