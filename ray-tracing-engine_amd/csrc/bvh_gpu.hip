@@ -23,8 +23,14 @@
 //   5. children are numbered by an exclusive scan over the level (breadth-first node
 //      order: the top of the tree is a prefix of the array, as the LDS-resident top wants),
 //      nodes are written packed with the plan's padding and plane scale.
-// Quality: contiguous Morton ranges are a subset of the partitions full SAH considers;
-// measured nodes/ray vs the host SAH tree are in DESIGN.md.  Cost: a few ms for 1 M triangles.
+//   6. (round 3) ranges of <= kSubMax triangles leave the Morton order: ONE WORKGROUP per range builds
+//      the whole subtree with the host builder's exact sweep — per level and axis a bitonic sort of
+//      the range's segments by centroid (LDS), segmented prefix / suffix box scans, the SAH cost of
+//      every split position, an atomic min per segment — and reorders the range's triangles; the
+//      subtrees are then numbered behind the top (scan of their node counts) and packed.
+//      Measured: a Morton-cut top over exact subtrees of <= 1,024 triangles is within
+//      -2 ... +4 % of the host tree's node visits per ray; Morton cuts all the way down cost +19 ... 29 %.
+// Quality: measured nodes/ray vs the host SAH tree are in DESIGN.md.  Cost: a few ms for 1 M triangles.
 #include <hip/hip_runtime.h>
 
 #include <cstring>  // (rocPRIM's headers use memset without including it)
@@ -42,6 +48,14 @@ namespace {
 struct WorkItem {
   uint32_t b, e;  // Morton-order range
 };
+// a range small enough for the exact builder (k_subtree): its place in the tree is patched in afterwards
+struct SubItem {
+  uint32_t b, e;
+  uint32_t depth;        // depth of the subtree's root node
+  uint32_t parent;       // top node that refers to it (~0u: the subtree IS the tree), and which child
+  uint32_t slot;
+};
+constexpr uint32_t kSubMax = 1024;  // triangles per exact subtree (one workgroup, one triangle per thread)
 
 __device__ __forceinline__ int fkey(float f) {  // order-preserving float -> int
   const int i = __float_as_int(f);
@@ -191,7 +205,8 @@ __device__ __forceinline__ uint32_t half_directed(float x, bool up) {
 __global__ __launch_bounds__(256) void k_level_split(const WorkItem* __restrict__ items, uint32_t count, uint32_t depth, int depthCap,
                                                      uint32_t leafMax, const float4* __restrict__ segLo,
                                                      const float4* __restrict__ segHi, uint32_t N2, const uint64_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ splitPos, uint32_t* __restrict__ innerCnt) {
+                                                     uint32_t* __restrict__ splitPos, uint32_t* __restrict__ innerCnt,
+                                                     uint32_t* __restrict__ subCnt, uint32_t subMax) {
   const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (w >= count) return;
   const uint32_t b = items[w].b, e = items[w].e, n = e - b;
@@ -262,7 +277,10 @@ __global__ __launch_bounds__(256) void k_level_split(const WorkItem* __restrict_
     uint32_t kk = (uint32_t)key;
     if ((uint32_t)(key >> 32) >= 0x7f800000u) kk = b + n / 2u;  // no finite candidate: the median always fits the budget
     splitPos[w] = kk;
-    innerCnt[w] = (kk - b > leafMax ? 1u : 0u) + (e - kk > leafMax ? 1u : 0u);
+    // children: leaves (<= leafMax), exact subtrees (<= subMax), or work items of the next level
+    const uint32_t n0 = kk - b, n1 = e - kk;
+    innerCnt[w] = (n0 > leafMax && n0 > subMax ? 1u : 0u) + (n1 > leafMax && n1 > subMax ? 1u : 0u);
+    subCnt[w] = (n0 > leafMax && n0 <= subMax ? 1u : 0u) + (n1 > leafMax && n1 <= subMax ? 1u : 0u);
   }
 }
 
@@ -270,15 +288,21 @@ __global__ __launch_bounds__(256) void k_level_split(const WorkItem* __restrict_
 __global__ void k_level_emit(const WorkItem* __restrict__ items, uint32_t count, uint32_t levelBase, uint32_t nextBase,
                              const uint32_t* __restrict__ splitPos, const uint32_t* __restrict__ innerOff, uint32_t leafMax,
                              const float4* __restrict__ segLo, const float4* __restrict__ segHi, uint32_t N2, float pad,
-                             float boxScale, uint4* __restrict__ nodes16, float4* __restrict__ nodesF, WorkItem* __restrict__ next) {
+                             float boxScale, uint4* __restrict__ nodes16, float4* __restrict__ nodesF, WorkItem* __restrict__ next,
+                             const uint32_t* __restrict__ subOff, uint32_t subBase, SubItem* __restrict__ subs, uint32_t subMax,
+                             uint32_t depth) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= count) return;
   const uint32_t b = items[w].b, e = items[w].e, k = splitPos[w];
-  uint32_t slot = innerOff[w];
+  uint32_t slot = innerOff[w], sslot = subBase + subOff[w];
   int32_t child[2];
   const uint32_t cb[2] = {b, k}, ce[2] = {k, e};
   for (int c = 0; c < 2; ++c) {
-    if (ce[c] - cb[c] > leafMax) {
+    if (ce[c] - cb[c] > leafMax && ce[c] - cb[c] <= subMax) {
+      subs[sslot] = SubItem{cb[c], ce[c], depth + 1u, levelBase + w, (uint32_t)c};
+      child[c] = 0;  // (patched by k_sub_relocate once the subtree's root has its index)
+      ++sslot;
+    } else if (ce[c] - cb[c] > leafMax) {
       next[slot] = WorkItem{cb[c], ce[c]};
       child[c] = (int32_t)(nextBase + slot);
       ++slot;
@@ -323,6 +347,275 @@ __global__ void k_tri_records(const float* __restrict__ vpos, const uint4* __res
   recs[3 * (size_t)i + 2] = make_float4(e2z, __uint_as_float(t), __uint_as_float(tv.w), 0.f);
 }
 
+// ---------------------------------------------------------------- exact subtrees (step 6)
+// One workgroup of T threads builds the whole subtree over a range of n <= T triangles, one triangle
+// per thread, level by level; all segments (sub-ranges that still need a split) of a level are handled
+// at once.  Per level:
+//   for each axis: bitonic sort of the positions by (segment, centroid, position) — segments keep their
+//     index ranges, so this sorts every segment by itself —, segmented suffix / prefix scans of the boxes
+//     in sorted order, the host builder's cost `area(left) * ceil(nl / leafMax) + area(right) * ceil(nr /
+//     leafMax)` at every split position that still fits the depth budget, atomic min per segment of
+//     (cost, axis, position) — lowest cost, then lowest axis, then lowest position: bvh_build.cpp's sweep;
+//   then every triangle moves to its rank along its segment's best axis, the segments split, their child
+//   boxes come from one more segmented scan, new inner nodes are numbered by a scan (breadth-first inside
+//   the subtree: deterministic), the node records go to the subtree's scratch block.
+// Leaves keep their triangles in ascending id order (as the host builder's).
+struct SubShared {
+  // laid out by subtree_lds(): see k_subtree
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items, const uint32_t* __restrict__ scratchOff,
+                                               uint32_t* __restrict__ order, const float4* __restrict__ triLo,
+                                               const float4* __restrict__ triHi, uint32_t leafMax, int depthCap,
+                                               float4* __restrict__ scratch, uint32_t* __restrict__ cntOut,
+                                               uint32_t* __restrict__ heightOut) {
+  extern __shared__ unsigned long long sub_lds[];
+  // LDS carve-up (T = 1024: 8 + 8 + 36 + 4 + 24 + 4 + 6 + 10 KB = 100 KB)
+  unsigned long long* key = sub_lds;                  // [T] sort keys
+  unsigned long long* best = key + T;                 // [T] per segment start: (cost bits << 32 | axis << 16 | split position)
+  float* eLo = reinterpret_cast<float*>(best + T);    // [3][T] element boxes, centroids (position order)
+  float* eHi = eLo + 3 * T;
+  float* eCen = eHi + 3 * T;
+  uint32_t* eTid = reinterpret_cast<uint32_t*>(eCen + 3 * T);  // [T] triangle (reference index)
+  float* sc = reinterpret_cast<float*>(eTid + T);     // [6][T] scan buffer
+  float* sufA = sc + 6 * T;                           // [T] area of the suffix box
+  uint16_t* rnk = reinterpret_cast<uint16_t*>(sufA + T);  // [3][T] rank of each position along each axis
+  uint16_t* segS = rnk + 3 * T;                       // [T] segment [segS, segE) of the element at this position
+  uint16_t* segE = segS + T;
+  uint16_t* segNode = segE + T;                       // [T] local node index of the segment (all its positions carry it)
+  uint16_t* segDep = segNode + T;                     // [T] depth of that node
+  uint16_t* scan16 = segDep + T;                      // [T] flag scan
+  __shared__ uint32_t nodeCount, anySplit, maxDep;
+
+  const SubItem it = items[blockIdx.x];
+  const uint32_t n = it.e - it.b, i = threadIdx.x;
+  float4* const out = scratch + 4 * (size_t)scratchOff[blockIdx.x];
+  const float inf = __int_as_float(0x7f800000);
+  if (i < n) {
+    const uint32_t t = order[it.b + i];
+    const float4 l = triLo[t], h = triHi[t];
+    eLo[i] = l.x, eLo[T + i] = l.y, eLo[2 * T + i] = l.z;
+    eHi[i] = h.x, eHi[T + i] = h.y, eHi[2 * T + i] = h.z;
+    eCen[i] = 0.5f * l.x + 0.5f * h.x, eCen[T + i] = 0.5f * l.y + 0.5f * h.y, eCen[2 * T + i] = 0.5f * l.z + 0.5f * h.z;
+    eTid[i] = t;
+  }
+  segS[i] = 0, segE[i] = (uint16_t)n, segNode[i] = 0, segDep[i] = (uint16_t)it.depth;
+  if (i == 0) nodeCount = 1u, maxDep = it.depth;
+  __syncthreads();
+
+  auto gather_boxes = [&](bool) {
+    // sc[c][i] = box component c of the element that sits at sorted position i (key payload = its home position)
+    const uint32_t h = i < n ? (uint32_t)(key[i] & 1023u) : 0u;
+    for (int c = 0; c < 3; ++c) sc[c * T + i] = i < n ? eLo[c * T + h] : inf, sc[(3 + c) * T + i] = i < n ? eHi[c * T + h] : -inf;
+  };
+  auto scan_boxes = [&](bool suffix) {
+    // segmented inclusive scan (union of boxes) along the positions, never across a segment border
+    for (uint32_t d = 1; d < (uint32_t)T; d <<= 1) {
+      float v[6];
+      const bool take = suffix ? (i + d < segE[i]) : (i >= d + segS[i]);
+      const uint32_t j = suffix ? i + d : i - d;
+      for (int c = 0; c < 6; ++c) v[c] = sc[c * T + i];
+      if (take)
+        for (int c = 0; c < 3; ++c) v[c] = fminf(v[c], sc[c * T + j]), v[3 + c] = fmaxf(v[3 + c], sc[(3 + c) * T + j]);
+      __syncthreads();
+      for (int c = 0; c < 6; ++c) sc[c * T + i] = v[c];
+      __syncthreads();
+    }
+  };
+  auto area_at = [&](uint32_t j) {
+    const float dx = sc[3 * T + j] - sc[j], dy = sc[4 * T + j] - sc[T + j], dz = sc[5 * T + j] - sc[2 * T + j];
+    return dx < 0.f ? 0.f : dx * dy + dy * dz + dz * dx;
+  };
+
+  for (;;) {
+    // ---- anything left to split?
+    if (i == 0) anySplit = 0u;
+    best[i] = ~0ull;
+    __syncthreads();
+    const bool big = i < n && (uint32_t)(segE[i] - segS[i]) > leafMax;
+    if (big && i == segS[i]) anySplit = 1u;
+    __syncthreads();
+    if (!anySplit) break;
+    // ---- the three sweeps
+    for (int a = 0; a < 3; ++a) {
+      uint32_t ck = 0;
+      if (i < n) {
+        const int fk = fkey(eCen[a * T + i]);
+        ck = (uint32_t)fk ^ 0x80000000u;  // order-preserving unsigned
+      }
+      key[i] = i < n ? ((unsigned long long)segS[i] << 42) | ((unsigned long long)ck << 10) | i : ~0ull;
+      __syncthreads();
+      for (uint32_t k = 2; k <= (uint32_t)T; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          const uint32_t x = i ^ j;
+          if (x > i) {
+            const unsigned long long ka = key[i], kb = key[x];
+            const bool up = (i & k) == 0;
+            if ((ka > kb) == up) key[i] = kb, key[x] = ka;
+          }
+          __syncthreads();
+        }
+      if (i < n) rnk[a * T + (uint32_t)(key[i] & 1023u)] = (uint16_t)i;
+      // suffix areas: sufA[j] = area of the box of sorted positions [j, segE)
+      gather_boxes(true);
+      __syncthreads();
+      scan_boxes(true);
+      sufA[i] = area_at(i);
+      __syncthreads();
+      gather_boxes(false);
+      __syncthreads();
+      scan_boxes(false);
+      // the split AFTER sorted position i: left = [segS, i + 1), right = [i + 1, segE)
+      if (big && i + 1u < segE[i]) {
+        const uint32_t s0 = segS[i], nl = i + 1u - s0, nr = segE[i] - i - 1u;
+        const int rem = depthCap - (int)segDep[i] - 1;
+        const unsigned long long maxSide = rem >= 31 ? ~0ull : (unsigned long long)leafMax << (rem < 0 ? 0 : rem);
+        if (nl <= maxSide && nr <= maxSide) {
+          const float cost = area_at(i) * (float)((nl + leafMax - 1u) / leafMax) + sufA[i + 1u] * (float)((nr + leafMax - 1u) / leafMax);
+          if (cost == cost && cost >= 0.f)
+            atomicMin(&best[s0], ((unsigned long long)__float_as_uint(cost) << 32) | ((unsigned long long)a << 16) | (i + 1u));
+        }
+      }
+      __syncthreads();
+    }
+    // ---- decisions: (axis, split position) per segment; no admissible split (depth budget): the median of the
+    // current order always fits it
+    uint32_t ax = 0, kpos = 0;
+    if (big) {
+      const unsigned long long bb = best[segS[i]];
+      if (bb == ~0ull) ax = 3u, kpos = segS[i] + (uint32_t)(segE[i] - segS[i]) / 2u;
+      else ax = (uint32_t)(bb >> 16) & 3u, kpos = (uint32_t)bb & 0xffffu;
+    }
+    // ---- every triangle to its rank along the chosen axis (ax == 3: stays)
+    const uint32_t np = (big && ax < 3u) ? rnk[ax * T + i] : i;
+    float m[9];
+    uint32_t mt = 0;
+    uint16_t ms = 0, me = 0, mn = 0, md = 0;
+    if (i < n) {
+      for (int c = 0; c < 3; ++c) m[c] = eLo[c * T + i], m[3 + c] = eHi[c * T + i], m[6 + c] = eCen[c * T + i];
+      mt = eTid[i], ms = segS[i], me = segE[i], mn = segNode[i], md = segDep[i];
+    }
+    __syncthreads();
+    if (i < n) {
+      for (int c = 0; c < 3; ++c) eLo[c * T + np] = m[c], eHi[c * T + np] = m[3 + c], eCen[c * T + np] = m[6 + c];
+      eTid[np] = mt;
+      // the new segment of this triangle, its parent's node and which child it is (in segNode's high bit for now)
+      if (big) {
+        const bool right = np >= kpos;
+        segS[np] = right ? (uint16_t)kpos : ms, segE[np] = right ? me : (uint16_t)kpos;
+        segDep[np] = (uint16_t)(md + 1u);
+        segNode[np] = (uint16_t)(mn | (right ? 0x8000u : 0u));  // parent's node, child slot
+      } else {
+        segS[np] = ms, segE[np] = me, segDep[np] = md, segNode[np] = 0xffffu;  // a finished leaf: nothing to emit
+      }
+    }
+    __syncthreads();
+    // ---- boxes of the new segments: prefix scan in position order, the value at the segment's last position
+    for (int c = 0; c < 3; ++c) sc[c * T + i] = i < n ? eLo[c * T + i] : inf, sc[(3 + c) * T + i] = i < n ? eHi[c * T + i] : -inf;
+    __syncthreads();
+    scan_boxes(false);
+    // ---- number the new inner nodes (segment starts of segments that still exceed a leaf), in position order
+    const bool fresh = i < n && segNode[i] != 0xffffu;            // belongs to a segment created by this level
+    const bool starts = fresh && i == segS[i];
+    const bool inner = starts && (uint32_t)(segE[i] - segS[i]) > leafMax;
+    scan16[i] = inner ? 1u : 0u;
+    __syncthreads();
+    for (uint32_t d = 1; d < (uint32_t)T; d <<= 1) {
+      const uint16_t v = i >= d ? scan16[i - d] : 0;
+      __syncthreads();
+      scan16[i] = (uint16_t)(scan16[i] + v);
+      __syncthreads();
+    }
+    const uint32_t base = nodeCount;
+    __syncthreads();
+    // ---- the parents' records: child box + child ref, written by the first position of each new segment
+    if (starts) {
+      const uint32_t s0 = segS[i], e0 = segE[i], last = e0 - 1u;
+      const uint32_t parent = segNode[i] & 0x7fffu, slot = segNode[i] >> 15;
+      int32_t ref;
+      if (inner) ref = (int32_t)(base + scan16[i] - 1u);
+      else ref = ~(int32_t)(((it.b + s0) << 3) | (e0 - s0 - 1u));
+      float* rec = reinterpret_cast<float*>(out + 4 * (size_t)parent);  // rtbvh::Node: lo0 hi0 lo1 hi1 child[2] pad[2]
+      for (int c = 0; c < 3; ++c) rec[6 * slot + c] = sc[c * T + last], rec[6 * slot + 3 + c] = sc[(3 + c) * T + last];
+      reinterpret_cast<int32_t*>(rec)[12 + slot] = ref;
+      if (slot == 0) rec[14] = 0.f, rec[15] = 0.f;
+      atomicMax(&maxDep, (uint32_t)segDep[i]);
+    }
+    __syncthreads();
+    // the new segments carry their own node index from now on
+    if (fresh) {
+      const uint32_t s0 = segS[i];
+      const bool in = (uint32_t)(segE[i] - s0) > leafMax;
+      // (the index was computed by the segment's first position: read it back through the scan)
+      segNode[i] = in ? (uint16_t)(base + scan16[s0] - 1u) : (uint16_t)0xffffu;
+    }
+    if (i == T - 1) nodeCount = base + scan16[T - 1];
+    __syncthreads();
+  }
+  // ---- leaves: ascending triangle index inside a leaf, then the range's new order
+  if (i < n && i == segS[i]) {
+    const uint32_t s0 = segS[i], e0 = segE[i];
+    for (uint32_t x = s0 + 1u; x < e0; ++x) {
+      const uint32_t v = eTid[x];
+      uint32_t y = x;
+      while (y > s0 && eTid[y - 1u] > v) eTid[y] = eTid[y - 1u], --y;
+      eTid[y] = v;
+    }
+  }
+  __syncthreads();
+  if (i < n) order[it.b + i] = eTid[i];
+  if (i == 0) {
+    cntOut[blockIdx.x] = nodeCount;
+    atomicMax(heightOut, maxDep);
+  }
+}
+
+constexpr size_t subtree_lds_bytes(int T) { return (size_t)T * (8 + 8 + 36 + 4 + 24 + 4 + 6 + 12); }
+
+// scratch -> final arrays: subtree i's nodes go to [base[i], base[i] + cnt[i]), inner refs shifted, boxes padded
+// and packed; the top node that refers to the subtree gets its root's index.
+__global__ void k_sub_relocate(const SubItem* __restrict__ items, const uint32_t* __restrict__ scratchOff, const uint32_t* __restrict__ cnt,
+                               const uint32_t* __restrict__ finalOff, uint32_t nTop, const float4* __restrict__ scratch, float pad,
+                               float boxScale, uint4* __restrict__ nodes16, float4* __restrict__ nodesF) {
+  const SubItem it = items[blockIdx.x];
+  const uint32_t base = nTop + finalOff[blockIdx.x], c = cnt[blockIdx.x];
+  const float4* src = scratch + 4 * (size_t)scratchOff[blockIdx.x];
+  for (uint32_t k = threadIdx.x; k < c; k += blockDim.x) {
+    float r[16];
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = src[4 * (size_t)k + q];
+      r[4 * q] = v.x, r[4 * q + 1] = v.y, r[4 * q + 2] = v.z, r[4 * q + 3] = v.w;
+    }
+    int32_t child[2] = {__float_as_int(r[12]), __float_as_int(r[13])};
+    for (int q = 0; q < 2; ++q)
+      if (child[q] >= 0) child[q] += (int32_t)base;
+    Box3 B0{r[0] - pad, r[1] - pad, r[2] - pad, r[3] + pad, r[4] + pad, r[5] + pad};
+    Box3 B1{r[6] - pad, r[7] - pad, r[8] - pad, r[9] + pad, r[10] + pad, r[11] + pad};
+    const size_t i = base + k;
+    nodesF[4 * i + 0] = make_float4(B0.lx, B0.ly, B0.lz, B0.hx);
+    nodesF[4 * i + 1] = make_float4(B0.hy, B0.hz, B1.lx, B1.ly);
+    nodesF[4 * i + 2] = make_float4(B1.lz, B1.hx, B1.hy, B1.hz);
+    nodesF[4 * i + 3] = make_float4(__int_as_float(child[0]), __int_as_float(child[1]), 0.f, 0.f);
+    const float s = boxScale;
+    const uint32_t h[12] = {half_directed(B0.lx * s, false), half_directed(B0.hx * s, true), half_directed(B0.ly * s, false),
+                            half_directed(B0.hy * s, true),  half_directed(B0.lz * s, false), half_directed(B0.hz * s, true),
+                            half_directed(B1.lx * s, false), half_directed(B1.hx * s, true), half_directed(B1.ly * s, false),
+                            half_directed(B1.hy * s, true),  half_directed(B1.lz * s, false), half_directed(B1.hz * s, true)};
+    nodes16[2 * i + 0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+    nodes16[2 * i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, packed_ref(child[0]), packed_ref(child[1]));
+  }
+  if (threadIdx.x == 0 && it.parent != ~0u) {
+    // the referring top node: float form child[slot] (word 12 + slot) and packed form (word 6 + slot of the 8)
+    reinterpret_cast<int32_t*>(nodesF)[16 * (size_t)it.parent + 12 + it.slot] = (int32_t)base;
+    reinterpret_cast<uint32_t*>(nodes16)[8 * (size_t)it.parent + 6 + it.slot] = base * 32u;
+  }
+}
+__global__ void k_sub_sizes(const SubItem* __restrict__ items, uint32_t n, uint32_t* __restrict__ sizes) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sizes[i] = items[i].e - items[i].b - 1u;  // a binary tree over m triangles has at most m - 1 inner nodes
+}
+
 #define GB_TRY(expr)            \
   do {                          \
     hipError_t e_ = (expr);     \
@@ -348,11 +641,17 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
   uint64_t *keys = nullptr, *keys2 = nullptr;
   uint32_t *vals = nullptr, *order = nullptr, *splitPos = nullptr, *innerCnt = nullptr, *innerOff = nullptr;
   WorkItem *itemsA = nullptr, *itemsB = nullptr;
+  SubItem* subs = nullptr;
+  uint32_t *subCnt = nullptr, *subOff = nullptr, *subSizes = nullptr, *scratchOff = nullptr, *subNodes = nullptr, *finalOff = nullptr,
+           *height = nullptr;
+  float4* scratch = nullptr;
   void* tmp = nullptr;
   bool keepOutputs = false;
+  static const uint32_t subMax = getenv("RT_BVH_GPU_SUB") ? (uint32_t)atoi(getenv("RT_BVH_GPU_SUB")) : kSubMax;  // 0: Morton cuts all the way down
   auto cleanup = [&]() {
     for (void* p : {(void*)lo, (void*)hi, (void*)segLo, (void*)segHi, (void*)cb, (void*)keys, (void*)keys2, (void*)vals, (void*)order,
-                    (void*)splitPos, (void*)innerCnt, (void*)innerOff, (void*)itemsA, (void*)itemsB, tmp})
+                    (void*)splitPos, (void*)innerCnt, (void*)innerOff, (void*)itemsA, (void*)itemsB, (void*)subs, (void*)subCnt,
+                    (void*)subOff, (void*)subSizes, (void*)scratchOff, (void*)subNodes, (void*)finalOff, (void*)height, (void*)scratch, tmp})
       if (p) (void)hipFree(p);
     if (!keepOutputs)
       for (void* p : {(void*)nodes16, (void*)nodesF, (void*)tris, (void*)trisRef})
@@ -373,6 +672,16 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
   GB_TRY(hipMalloc((void**)&innerOff, (size_t)maxNodes * sizeof(uint32_t)));
   GB_TRY(hipMalloc((void**)&itemsA, (size_t)maxNodes * sizeof(WorkItem)));
   GB_TRY(hipMalloc((void**)&itemsB, (size_t)maxNodes * sizeof(WorkItem)));
+  GB_TRY(hipMalloc((void**)&subs, (size_t)maxNodes * sizeof(SubItem)));
+  GB_TRY(hipMalloc((void**)&subCnt, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&subOff, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&subSizes, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&scratchOff, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&subNodes, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&finalOff, (size_t)maxNodes * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&height, sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&scratch, 4 * (size_t)maxNodes * sizeof(float4)));
+  GB_TRY(hipMemsetAsync(height, 0, sizeof(uint32_t), stream));
   GB_TRY(hipMalloc((void**)&nodes16, 2 * (size_t)maxNodes * sizeof(uint4)));
   GB_TRY(hipMalloc((void**)&nodesF, 4 * (size_t)maxNodes * sizeof(float4)));
   GB_TRY(hipMalloc((void**)&tris, 3 * (size_t)n * sizeof(float4)));
@@ -391,13 +700,15 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
   hipLaunchKernelGGL(k_seg_leaves, dim3((N2 + 255) / 256), blk, 0, stream, lo, hi, order, n, N2, segLo, segHi);
   for (uint32_t cnt = N2 / 2; cnt >= 1; cnt >>= 1)  // level with `cnt` nodes starts at index cnt
     hipLaunchKernelGGL(k_seg_level, dim3((cnt + 255) / 256), blk, 0, stream, cnt, cnt, segLo, segHi);
-  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
-  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
-
-  // top-down, one level at a time
+  // top-down, one level at a time; ranges of <= subMax triangles become items of the exact builder
   const WorkItem root{0u, n};
   GB_TRY(hipMemcpyAsync(itemsA, &root, sizeof root, hipMemcpyHostToDevice, stream));
-  uint32_t count = 1, levelBase = 0, depth = 0, maxDepth = 0;
+  uint32_t count = 1, levelBase = 0, depth = 0, maxDepth = 0, nSub = 0;
+  if (n <= subMax) {  // the whole scene is one exact subtree
+    const SubItem whole{0u, n, 0u, ~0u, 0u};
+    GB_TRY(hipMemcpyAsync(subs, &whole, sizeof whole, hipMemcpyHostToDevice, stream));
+    nSub = 1, count = 0;
+  }
   WorkItem *cur = itemsA, *nxt = itemsB;
   while (count) {
     if ((int)depth >= rtbvh::kMaxDepth - 1 || levelBase + count > maxNodes) {
@@ -405,26 +716,64 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
       return hipErrorInvalidValue;  // (cannot happen: the depth budget is enforced by the split choice)
     }
     hipLaunchKernelGGL(k_level_split, dim3((count + 3) / 4), dim3(256), 0, stream, cur, count, depth, P.depthCap, leafMax, segLo,
-                       segHi, N2, keys2, splitPos, innerCnt);
+                       segHi, N2, keys2, splitPos, innerCnt, subCnt, subMax);
     GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, innerCnt, innerOff, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream));
+    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subCnt, subOff, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream));
     const uint32_t nextBase = levelBase + count;
     hipLaunchKernelGGL(k_level_emit, dim3((count + 255) / 256), blk, 0, stream, cur, count, levelBase, nextBase, splitPos, innerOff,
-                       leafMax, segLo, segHi, N2, P.pad, P.boxScale, nodes16, nodesF, nxt);
-    uint32_t lastOff = 0, lastCnt = 0;
+                       leafMax, segLo, segHi, N2, P.pad, P.boxScale, nodes16, nodesF, nxt, subOff, nSub, subs, subMax, depth);
+    uint32_t lastOff = 0, lastCnt = 0, lastSubOff = 0, lastSubCnt = 0;
     GB_TRY(hipMemcpyAsync(&lastOff, innerOff + (count - 1), 4, hipMemcpyDeviceToHost, stream));
     GB_TRY(hipMemcpyAsync(&lastCnt, innerCnt + (count - 1), 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipMemcpyAsync(&lastSubOff, subOff + (count - 1), 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipMemcpyAsync(&lastSubCnt, subCnt + (count - 1), 4, hipMemcpyDeviceToHost, stream));
     GB_TRY(hipStreamSynchronize(stream));
     maxDepth = depth + 1;  // leaves hang one level below the deepest inner level
     levelBase = nextBase;
     count = lastOff + lastCnt;
+    nSub += lastSubOff + lastSubCnt;
     ++depth;
     WorkItem* t = cur;
     cur = nxt, nxt = t;
   }
+  uint32_t nTotal = levelBase;
+  if (nSub) {
+    // the exact subtrees: scratch blocks of (triangles - 1) node slots each, built one workgroup per range ...
+    hipLaunchKernelGGL(k_sub_sizes, dim3((nSub + 255) / 256), blk, 0, stream, subs, nSub, subSizes);
+    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subSizes, scratchOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
+    static bool ldsSet = false;
+    const size_t ldsBytes = subtree_lds_bytes((int)kSubMax);
+    if (!ldsSet) {
+      GB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_subtree<(int)kSubMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)ldsBytes));
+      ldsSet = true;
+    }
+    hipLaunchKernelGGL((k_subtree<(int)kSubMax>), dim3(nSub), dim3(kSubMax), ldsBytes, stream, subs, scratchOff, order, lo, hi, leafMax,
+                       P.depthCap, scratch, subNodes, height);
+    // ... then numbered behind the top in item order (deterministic) and packed
+    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subNodes, finalOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(k_sub_relocate, dim3(nSub), blk, 0, stream, subs, scratchOff, subNodes, finalOff, levelBase, scratch, P.pad,
+                       P.boxScale, nodes16, nodesF);
+    uint32_t lastOff = 0, lastCnt = 0, h = 0;
+    GB_TRY(hipMemcpyAsync(&lastOff, finalOff + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipMemcpyAsync(&lastCnt, subNodes + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipMemcpyAsync(&h, height, 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipStreamSynchronize(stream));
+    nTotal = levelBase + lastOff + lastCnt;
+    maxDepth = maxDepth > h ? maxDepth : h;
+    if (nTotal > maxNodes) {
+      cleanup();
+      return hipErrorInvalidValue;
+    }
+  }
+  // triangle records in the FINAL leaf order (the exact builder has reordered its ranges), and in reference order
+  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
+  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
+  GB_TRY(hipStreamSynchronize(stream));
   GB_TRY(hipGetLastError());
   keepOutputs = true;
   out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;
-  out->n_nodes = levelBase, out->maxDepth = maxDepth;
+  out->n_nodes = nTotal, out->maxDepth = maxDepth;
   cleanup();
   return hipSuccess;
 }

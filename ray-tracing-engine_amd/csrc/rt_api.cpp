@@ -400,7 +400,10 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   c->device = opt ? opt->device : 0;
   // the tree: host SAH builder, or the device builder (tiny scenes always take the host's
   // special cases)
-  const bool gpuBuild = ((opt && opt->bvh_builder == RT_BVH_DEVICE) || getenv("RT_BVH_GPU")) && sc->n_triangles >= 16;
+  // (the 4-wide form is collapsed from the host builder's float nodes: asking for it selects the host builder)
+  const char* wideEnv = getenv("RT_BVH_WIDE");
+  const bool wideWanted = wideEnv ? atoi(wideEnv) != 0 : (opt && opt->bvh_width == 4);
+  const bool gpuBuild = ((opt && opt->bvh_builder == RT_BVH_DEVICE) || getenv("RT_BVH_GPU")) && sc->n_triangles >= 16 && !wideWanted;
   rtbvh::ScenePlan plan;
   const auto tBuild0 = std::chrono::steady_clock::now();
   try {
@@ -416,14 +419,9 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     // Measured on MI355X: 0.71x the node visits but 4 instead of 2 vector-memory
     // requests per visit, and the CU's vector L1 — which serves ~0.7-0.9 divergent 16-B requests per
     // clock whatever their hit level — is what binds the big scenes: 1 M triangles 407 vs 357 ms.
-    if (!gpuBuild && c->bvh.nodes4.empty()) {
-      const char* we = getenv("RT_BVH_WIDE");
-      const uint32_t width = opt ? opt->bvh_width : 0;
-      const bool wide = we ? atoi(we) != 0 : width == 4;
-      if (wide) {
-        const char* wb = getenv("RT_BVH_WIDE_BUDGET");
-        rtbvh::collapse4(c->bvh, wb ? (uint32_t)atoi(wb) : 0u);
-      }
+    if (!gpuBuild && wideWanted && c->bvh.nodes4.empty()) {
+      const char* wb = getenv("RT_BVH_WIDE_BUDGET");
+      rtbvh::collapse4(c->bvh, wb ? (uint32_t)atoi(wb) : 0u);
     }
   } catch (const std::exception& e) {
     delete c;

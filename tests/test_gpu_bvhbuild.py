@@ -94,9 +94,10 @@ def test_frames_on_device_built_tree_vs_oracle(kind, w, h, spp):
 
 
 def test_build_time_and_tree_quality_report(capsys):
-    """Reported, with loose guards: the device build of the 1M-triangle scene must beat the
-    host build's time, and its traversal cost (nodes per ray on a fixed ray batch) must
-    stay within 1.35x of the host SAH tree's (measured values go to DESIGN.md)."""
+    """The device build of the 1M-triangle scene must beat the host build's time, and — since the exact
+    subtree builder of round 3 (bvh_gpu.hip k_subtree) — its traversal cost (nodes per ray of a
+    256x256x4 frame) must stay within 1.06x of the host SAH tree's (measured: lowres 0.99x, hires 0.95x,
+    stress 1.05x; Morton cuts all the way down, RT_BVH_GPU_SUB=0, were 1.29x / 1.17x / 1.19x)."""
     rows = []
     for kind, n in (("lowres", 200000), ("hires", 200000), ("stress", 200000)):
         s = pyrt.Scene(kind, 256, 256)
@@ -117,7 +118,7 @@ def test_build_time_and_tree_quality_report(capsys):
                   % ((kind,) + out["host"] + out["device"]), end="")
         print()
     for kind, out in rows:
-        assert out["device"][3] < 1.35 * out["host"][3], (kind, out)
+        assert out["device"][3] < 1.06 * out["host"][3], (kind, out)
     stress = dict(rows)["stress"]
     if not os.environ.get("RT_BVH_GPU"):  # (the variable forces the device builder for "host" too)
         assert stress["device"][0] < stress["host"][0]
