@@ -56,6 +56,13 @@ WORKLOADS = {
     "C5x8": ("stress8", 1024, 1024, 32, 1, 0, 0),
 }
 HBM_BOUND = ("C5", "C5x8")
+# The vector L1 (TCP) of a CU serves a bounded number of DIVERGENT 16-byte requests per clock, whatever their hit
+# level: measured by tools/microbench/gather.hip (profiles/r03_gather_microbench.json): 0.93 per CU-clock when every
+# request hits L1, 0.72 when they miss to L2 (3.9 when all lanes of a wave ask for the same address).  BVH traversal
+# beyond the LDS-resident scenes is bound by exactly this unit.
+TCP_DIVERGENT_PEAK = 0.93
+TCP_DIVERGENT_PEAK_L1_MISS = 0.72
+NUM_CUS = 256
 
 
 def kernel_source_hash():
@@ -78,7 +85,8 @@ def metric_text(wl):
 # ----------------------------------------------------------------------------- PMC passes
 PMC_PASSES = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVES",
                "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
-              ["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE"]]
+              ["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE"],
+              ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"]]
 
 
 def is_timed_render_kernel(name):
@@ -365,13 +373,13 @@ def main():
     # counters: this run's, or (fallback) a committed profile of the SAME device code
     khash = kernel_source_hash()
     if pmc is None:
-        ppath = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.workload)
+        ppath = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % args.workload)
         if os.path.exists(ppath) and not args.spp and world == 1 and args.accel == "bvh":
             saved = json.load(open(ppath))
             if saved.get("kernel_source_hash") == khash:
-                pmc, pmc_source = saved["counters"], "profiles/r02_pmc_%s.json @ kernel hash %s [%s]" % (args.workload, khash, pmc_source)
+                pmc, pmc_source = saved["counters"], "profiles/r03_pmc_%s.json @ kernel hash %s [%s]" % (args.workload, khash, pmc_source)
             else:
-                pmc_source = "profiles/r02_pmc_%s.json is for kernel hash %s, this build is %s: not used [%s]" % (
+                pmc_source = "profiles/r03_pmc_%s.json is for kernel hash %s, this build is %s: not used [%s]" % (
                     args.workload, saved.get("kernel_source_hash"), khash, pmc_source)
     hbm_bytes = valu = lane_util = None
     if pmc:
@@ -392,6 +400,15 @@ def main():
         valu_roof = {"bound": "valu_issue", "achieved": (valu / secs / 1e9) if valu and secs > 0 else None,
                      "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s"}
         valu_roof["frac"] = valu_roof["achieved"] / VALU_PEAK_GINSTR if valu_roof["achieved"] is not None else None
+        # vector-L1 request rate: TCP cache accesses per CU-clock of the timed kernel (clock from GRBM_GUI_ACTIVE, which
+        # rocprofv3 sums over the 8 XCDs)
+        tcp = None
+        if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum") and pmc.get("GRBM_GUI_ACTIVE"):
+            tcp = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * NUM_CUS)
+        tcp_roof = {"bound": "vector_l1_divergent_requests", "achieved": tcp, "peak": TCP_DIVERGENT_PEAK,
+                    "peak_when_missing_l1": TCP_DIVERGENT_PEAK_L1_MISS, "unit": "cache accesses per CU-clock",
+                    "frac": (tcp / TCP_DIVERGENT_PEAK) if tcp is not None else None,
+                    "peak_source": "tools/microbench/gather.hip on MI355X: profiles/r03_gather_microbench.json"}
         primary = hbm_roof if args.workload in HBM_BOUND else valu_roof
         roof = dict(primary)
         roof.update({
@@ -400,7 +417,7 @@ def main():
             "scope": "one launch of rank 0's shard (1/%d of the pixels)" % world if world > 1 else "one launch (whole frame)",
             "kernel": "k_render_persist" if args.accel == "bvh" and not nph else "k_render",
             "kernel_ms_avg": avg_ms, "launches": launches,
-            "valu_issue": valu_roof, "hbm": hbm_roof,
+            "valu_issue": valu_roof, "hbm": hbm_roof, "vector_l1": tcp_roof,
             "valu_lane_utilisation": lane_util,
             # what the caches served: SURVEY §8d's per-unit bytes x units; NOT an HBM fraction (the scene is
             # %.2f MB) — priced against HBM peak it may exceed 1, which only says the caches work
@@ -414,8 +431,9 @@ def main():
             "leaf_phases_per_node_step": st.reserved[1] / max(st.reserved[0], 1),
             "lanes_at_leaf_per_node_step": st.reserved[2] / max(st.reserved[0], 1),
             "lanes_without_ray_per_node_step": st.reserved[3] / max(st.reserved[0], 1),
-            "note": ("HBM-bound reading: measured FETCH/WRITE bytes; a scene below 256 MB is partly served by the Infinity "
-                     "Cache, whose hits these fabric-side counters still count" if args.workload in HBM_BOUND else
+            "note": ("HBM-side reading: measured FETCH/WRITE bytes; a scene below 256 MB is partly served by the Infinity "
+                     "Cache, whose hits these fabric-side counters still count.  What BINDS this traversal is roofline.vector_l1: "
+                     "the CU's vector L1 at its measured ceiling for divergent 16-B requests" if args.workload in HBM_BOUND else
                      "cache-resident scene: the binding unit is VALU issue under divergence, not any bandwidth; "
                      "frac = SQ_INSTS_VALU / s over 1024 SIMDs x 2.4 GHz / 2"),
         })
