@@ -93,6 +93,46 @@ def test_frames_on_device_built_tree_vs_oracle(kind, w, h, spp):
     ctx.close()
 
 
+def test_device_builder_variants_are_exact(tmp_path):
+    """The device builder's other configurations (environment knobs, read once per process): Morton cuts all the
+    way down (RT_BVH_GPU_SUB=0, round 2's tree), exact subtrees of <= 64 triangles, and the binned-SAH top
+    (RT_BVH_GPU_TOP=binned: k_top_split).  Every one must give the exhaustive loop's hits and the default tree's frame."""
+    import subprocess
+    import sys
+    script = tmp_path / "v.py"
+    script.write_text('''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1] + "/ray-tracing-engine_amd"); sys.path.insert(0, sys.argv[1] + "/tests")
+import pyrt
+from raybatch import ray_batch
+out = {}
+for kind, w, spp, n in (("lowres", 64, 4, 60000), ("hires", 48, 3, 60000), ("stress", 32, 2, 30000)):
+    s = pyrt.Scene(kind, w, w); ctx = pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE)
+    rays = ray_batch(s, n, 11)
+    got, want = ctx.trace(rays, pyrt.ACCEL_BVH), ctx.trace(rays, pyrt.ACCEL_BRUTE)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), kind
+    assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BVH, pyrt.TRACE_ANY)["hit"], want["hit"]), kind
+    _, acc, st = ctx.render(pyrt.make_params(w, w, spp, seed=9))
+    bi = ctx.bvh_info()
+    out[kind] = acc; out[kind + "_n"] = np.array([st.rays_closest, st.rays_shadow, bi.n_nodes, bi.max_depth])
+    ctx.close()
+np.savez(sys.argv[2], **out)
+''')
+    runs = {}
+    for name, env in (("default", {}), ("morton_all_the_way", {"RT_BVH_GPU_SUB": "0"}), ("subtrees_64", {"RT_BVH_GPU_SUB": "64"}),
+                      ("binned_top", {"RT_BVH_GPU_TOP": "binned"}), ("binned_top_64_bins", {"RT_BVH_GPU_TOP": "binned", "RT_BVH_GPU_BINS": "64"})):
+        out = tmp_path / (name + ".npz")
+        r = subprocess.run([sys.executable, str(script), pyrt.ROOT, str(out)], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        runs[name] = np.load(out)
+    for name in runs:
+        for kind in ("lowres", "hires", "stress"):
+            assert np.array_equal(bits(runs[name][kind]), bits(runs["default"][kind])), (name, kind)
+            assert np.array_equal(runs[name][kind + "_n"][:2], runs["default"][kind + "_n"][:2]), (name, kind)
+            assert runs[name][kind + "_n"][3] < 32
+
+
 def test_build_time_and_tree_quality_report(capsys):
     """The device build of the 1M-triangle scene must beat the host build's time, and — since the exact
     subtree builder of round 3 (bvh_gpu.hip k_subtree) — its traversal cost (nodes per ray of a
