@@ -788,6 +788,16 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
       out.maxDepth = R.height[0];  // (index 0 is the root before and after the relayout)
     }
   }
+  // Child 0 = the child with the SMALLER box: any-hit rays of the big-scene kernels enter it first (rt_kernels.hip
+  // Trav::round); closest-hit traversal orders by entry distance and does not care.
+  for (Node& n : out.nodes) {
+    Box b0, b1;
+    for (int a = 0; a < 3; ++a) b0.lo[a] = n.lo0[a], b0.hi[a] = n.hi0[a], b1.lo[a] = n.lo1[a], b1.hi[a] = n.hi1[a];
+    if (b1.halfArea() < b0.halfArea()) {
+      for (int a = 0; a < 3; ++a) std::swap(n.lo0[a], n.lo1[a]), std::swap(n.hi0[a], n.hi1[a]);
+      std::swap(n.child[0], n.child[1]);
+    }
+  }
   relayoutTop(out.nodes, kTopNodes);
   out.tris.resize(sc.n_triangles);
   for (uint32_t i = 0; i < sc.n_triangles; ++i) out.tris[i] = out.trisRef[B.prims[i].id];

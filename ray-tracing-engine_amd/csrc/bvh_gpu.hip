@@ -475,25 +475,32 @@ __global__ void k_level_emit(const WorkItem* __restrict__ items, uint32_t count,
   uint32_t slot = innerOff[w], sslot = subBase + subOff[w];
   int32_t child[2];
   const uint32_t cb[2] = {b, k}, ce[2] = {k, e};
-  for (int c = 0; c < 2; ++c) {
-    if (ce[c] - cb[c] > leafMax && ce[c] - cb[c] <= subMax) {
-      subs[sslot] = SubItem{cb[c], ce[c], depth + 1u, levelBase + w, (uint32_t)c};
-      child[c] = 0;  // (patched by k_sub_relocate once the subtree's root has its index)
-      ++sslot;
-    } else if (ce[c] - cb[c] > leafMax) {
-      next[slot] = WorkItem{cb[c], ce[c]};
-      child[c] = (int32_t)(nextBase + slot);
-      ++slot;
-    } else {
-      child[c] = ~(int32_t)((cb[c] << 3) | (ce[c] - cb[c] - 1u));
-    }
-  }
   Box3 B0, B1;
   if (childBoxes) {  // (binned top: the boxes the split kernel accumulated)
     const float* q = childBoxes + 12 * (size_t)w;
     B0 = Box3{q[0], q[1], q[2], q[3], q[4], q[5]}, B1 = Box3{q[6], q[7], q[8], q[9], q[10], q[11]};
   } else {
     B0 = range_box(segLo, segHi, N2, b, k), B1 = range_box(segLo, segHi, N2, k, e);
+  }
+  // child 0 = the smaller box (any-hit rays of the big-scene kernels enter it first: rt_kernels.hip Trav::round)
+  const bool swp = half_area(B1) < half_area(B0);
+  if (swp) {
+    const Box3 t = B0;
+    B0 = B1, B1 = t;
+  }
+  for (int c = 0; c < 2; ++c) {
+    const int o = swp ? 1 - c : c;  // the record's slot of range c
+    if (ce[c] - cb[c] > leafMax && ce[c] - cb[c] <= subMax) {
+      subs[sslot] = SubItem{cb[c], ce[c], depth + 1u, levelBase + w, (uint32_t)o};
+      child[o] = 0;  // (patched by k_sub_relocate once the subtree's root has its index)
+      ++sslot;
+    } else if (ce[c] - cb[c] > leafMax) {
+      next[slot] = WorkItem{cb[c], ce[c]};
+      child[o] = (int32_t)(nextBase + slot);
+      ++slot;
+    } else {
+      child[o] = ~(int32_t)((cb[c] << 3) | (ce[c] - cb[c] - 1u));
+    }
   }
   B0.lx -= pad, B0.ly -= pad, B0.lz -= pad, B0.hx += pad, B0.hy += pad, B0.hz += pad;
   B1.lx -= pad, B1.ly -= pad, B1.lz -= pad, B1.hx += pad, B1.hy += pad, B1.hz += pad;
@@ -776,6 +783,12 @@ __global__ void k_sub_relocate(const SubItem* __restrict__ items, const uint32_t
       if (child[q] >= 0) child[q] += (int32_t)base;
     Box3 B0{r[0] - pad, r[1] - pad, r[2] - pad, r[3] + pad, r[4] + pad, r[5] + pad};
     Box3 B1{r[6] - pad, r[7] - pad, r[8] - pad, r[9] + pad, r[10] + pad, r[11] + pad};
+    if (half_area(B1) < half_area(B0)) {  // child 0 = the smaller box (see k_level_emit)
+      const Box3 t = B0;
+      B0 = B1, B1 = t;
+      const int32_t c0 = child[0];
+      child[0] = child[1], child[1] = c0;
+    }
     const size_t i = base + k;
     nodesF[4 * i + 0] = make_float4(B0.lx, B0.ly, B0.lz, B0.hx);
     nodesF[4 * i + 1] = make_float4(B0.hy, B0.hz, B1.lx, B1.ly);
