@@ -203,7 +203,10 @@ struct Trav {
   static constexpr bool SS = (LTX & LT_SS) != 0;
   static constexpr bool PRIO = (LTX & LT_NOPRIO) == 0;
   static constexpr bool WIDE = (LTX & LT_WIDE) != 0;
-  static constexpr bool ANYORD = (LTX & LT_NOPRIO) != 0 && !WIDE;  // the big-scene instances (trees beyond kPrioMaxNodes)
+  // any-hit rays enter child 0 (the smaller box) first: the big-scene instances and the whole-tree-in-LDS ones (measured:
+  // C5 -2.5 %, C5x8 -1.9 %, C2 -0.7 %, C1 -3 %; the partial-top instance of C4 loses 0.7 % to the extra scalar op and keeps
+  // the distance order)
+  static constexpr bool ANYORD = !WIDE && ((LTX & LT_NOPRIO) != 0 || LT == LT_ALL);
   static_assert(!WIDE || (LT == LT_NONE && !SS), "wide nodes are fetched from HBM/L2 and use the plain LDS stack");
   f3 o, d, inv, oi;
   uint32_t rotX, rotY, rotZ;  // 16 where the direction component is negative (order_planes)
@@ -280,12 +283,11 @@ struct Trav {
     // (the lanes of a step are the ballot the loop control has just counted: the mask goes
     // straight back into exec — no second compare, no vector-to-scalar hand-over at the loop top)
     uint64_t inner = __builtin_amdgcn_ballot_w64(cur >= 0);
-    // Any-hit rays (Renderer.cpp:54 only uses the bool) do not need the nearer child first: on the big scenes they
+    // Any-hit rays (Renderer.cpp:54 only uses the bool) do not need the nearer child first: where ANYORD is set they
     // enter child 0 whenever it is hit — the builders put the SMALLER box there, the likelier place to find an occluder
     // close to the ray.  Same booleans, fewer visits: 1 M triangles 34.96 -> 33.54 nodes and 4.04 -> 3.50 triangle tests
-    // per ray, 357 -> 346 ms; 8 M triangles 58.7 -> 57.6 ms.  (Cache-resident scenes keep the distance order: +-0 on
-    // C2, +1 % on C4, and their step has no scalar instruction to spare.  Denser-subtree-first and larger-box-first
-    // lose: profiles/r03_anyhit_order_ab.txt.)
+    // per ray, 357 -> 348 ms; 8 M triangles 58.7 -> 57.6 ms; C2 3.17 -> 2.99 triangle tests per ray, 50.9 -> 50.6 ms.
+    // (Denser-subtree-first, larger-box-first and the RTSAH rule lose: profiles/r03_anyhit_order_ab.txt.)
     const uint64_t anyFirst = !ANYORD ? 0ull : MODE == TRAV_ANY ? ~0ull : MODE == TRAV_MIXED ? __builtin_amdgcn_ballot_w64(anyHit) : 0ull;
     if (PRIO) __builtin_amdgcn_s_setprio(2);
     if (inner) for (;;) {
