@@ -561,6 +561,7 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
                                                const float4* __restrict__ triHi, uint32_t leafMax, int depthCap,
                                                float4* __restrict__ scratch, uint32_t* __restrict__ cntOut,
                                                uint32_t* __restrict__ heightOut) {
+  static_assert(T <= 1024 && (T & (T - 1)) == 0, "positions are 10-bit payloads of the sort keys; the bitonic network wants a power of two");
   extern __shared__ unsigned long long sub_lds[];
   // LDS carve-up (T = 1024: 8 + 8 + 36 + 4 + 24 + 4 + 6 + 10 KB = 100 KB)
   unsigned long long* key = sub_lds;                  // [T] sort keys
