@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x)                                                                 \
@@ -57,7 +58,12 @@ static float run(const uint4* table, uint32_t recQuads, uint32_t nrec, uint32_t 
   return ms;
 }
 
+// `gather_bench one <table KB> <record bytes>`: one configuration (2 requests per record, one chain, 16 waves per CU) and
+// nothing else — what a rocprofv3 --pmc FETCH_SIZE pass is pointed at to see the HBM-side bytes a random record costs.
+static int one(size_t tableKB, uint32_t recBytes);
+
 int main(int argc, char** argv) {
+  if (argc >= 4 && !strcmp(argv[1], "one")) return one((size_t)atoll(argv[2]), (uint32_t)atoi(argv[3]));
   int cus = 0;
   CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
   uint32_t* sink;
@@ -110,5 +116,30 @@ int main(int argc, char** argv) {
     }
   }
   printf("\n]}\n");
+  return 0;
+}
+
+static int one(size_t tableKB, uint32_t recBytes) {
+  int cus = 0;
+  CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+  uint32_t* sink;
+  CK(hipMalloc(&sink, 256 * 1024 * 4 * 4));
+  const uint32_t recQuads = recBytes / 16u, nrec = (uint32_t)(tableKB * 1024u / recBytes);
+  std::vector<uint4> h((size_t)nrec * recQuads);
+  std::vector<uint32_t> perm(nrec);
+  for (uint32_t i = 0; i < nrec; ++i) perm[i] = i;
+  uint64_t st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13, st ^= st >> 7, st ^= st << 17; return st; };
+  for (uint32_t i = nrec - 1; i > 0; --i) std::swap(perm[i], perm[rnd() % i]);
+  for (uint32_t i = 0; i < nrec; ++i)
+    for (uint32_t q = 0; q < recQuads; ++q) h[(size_t)i * recQuads + q] = make_uint4(perm[i], i, q, 7u);
+  uint4* d;
+  CK(hipMalloc(&d, h.size() * sizeof(uint4)));
+  CK(hipMemcpy(d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice));
+  const uint32_t steps = 1024;
+  const float ms = run<2, 1>(d, recQuads, nrec, steps, 0, sink, cus, 16);
+  const double recs = (double)cus * 16 * 64 * steps;
+  printf("{\"table_kb\": %zu, \"rec_bytes\": %u, \"steps\": %u, \"records\": %.0f, \"ms\": %.3f, \"grec_per_s\": %.1f}\n", tableKB, recBytes, steps, recs,
+         ms, recs / (ms * 1e-3) / 1e9);
   return 0;
 }
