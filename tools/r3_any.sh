@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL: the variant this script measured was dropped and its switch is no longer in the code (results: profiles/r03_*.txt).
 cd "$GRAFT_REPO_ROOT"
 tools/run_guarded.sh gpurun_out/t_all.log 1100 python3 -m pytest tests -q -m gpu || exit 1
 tools/exp.sh ":: --workload C2 --no-pmc --steps 10" ":: --workload C4 --no-pmc --steps 2" ":: --workload C5 --no-pmc" > gpurun_out/ab_any6.log 2>&1
