@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL: RT_BVH_EMULATE_DEVICE (the host builder emulating the device top) was an experiment switch and is no longer in the code (results: profiles/r03_bvh_emulation_morton_top_exact_bottom.txt).
 cd "$GRAFT_REPO_ROOT"
 {
 for wl in C2 C4 C5; do
