@@ -137,7 +137,7 @@ int upload_owned(rt_ctx* c, const T** field, const void* src, size_t count) {
 // them in order.  More samples per wave = more, shorter work items: the grid no longer
 // quantises into ~3 rounds of 16k tile-sized items, and a rank that owns 1/8 of the
 // pixels still fills the GPU.
-uint32_t choose_sshift(const rt_params* p, uint32_t spp_count) {
+uint32_t choose_sshift(const rt_ctx* c, const rt_params* p, uint32_t spp_count) {
   if (p->reserved[0]) {  // explicit lanes-per-pixel (tests, experiments)
     uint32_t s = 0;
     while ((1u << (s + 1)) <= p->reserved[0] && s < 6) ++s;
@@ -151,6 +151,20 @@ uint32_t choose_sshift(const rt_params* p, uint32_t spp_count) {
   const uint64_t target = 32ull * 256 * 16;
   uint32_t s = 0;
   while (s < 6 && (pixels << s) / 64 < target && (2u << s) <= spp_count) ++s;
+  // The pooled BVH kernel (persistent workgroups: no grid quantisation to balance) wants MORE samples of a pixel side by
+  // side than that: their vertices lie close together, so the wave's rays share nodes and triangle lines.  Measured in
+  // round 3 (profiles/r03_samples_per_wave.txt), frame ms at 1 / 4 / 8 / 16 / 32 / 64 samples of a pixel per wave:
+  // C2 56.1 / 51.2 / 50.4 / 50.3 / 50.6 / 51.4, C4 - / 937.6 / 934.0 / 931.5 / - / 951.8 (the old rule gave it 2: 946),
+  // and the scenes that sit on the vector L1's request roof, where coalescing is worth most: 1 M triangles 407 / 358 /
+  // 348 / 339 / 334 / 328, 8 M triangles (32 spp) - / 59.7 / 57.6 / 55.8 / 55.1.  So: 16 on cache-resident scenes, as
+  // many as the frame has (<= 64) beyond 65,536 nodes.  (The owner lane's in-order adds grow with the count: that is
+  // what turns C2 and C4 around after 16.)  The image does not depend on it (test_frame_independent_of_samples_per_wave).
+  const bool pooled = !p->use_photons && p->accel != RT_ACCEL_BRUTE && c->S.n_lights <= 3u && !(p->reserved[1] & 1u) &&
+                      !(p->reserved[2] & 1u);
+  if (pooled) {
+    const uint32_t want = c->S.n_nodes > 65536u ? 6u : 4u;
+    while (s < want && (2u << s) <= spp_count) ++s;
+  }
   return s;
 }
 
@@ -268,7 +282,7 @@ int read_counters(rt_ctx* c, rt_stats* st) {
 // Launch the integrate kernel for p on `stream`, bracketed by an event pair.
 int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stream, int* evIndex) {
   const uint32_t sppCount = p->spp_count ? p->spp_count : p->spp;
-  const uint32_t sshift = choose_sshift(p, sppCount);
+  const uint32_t sshift = choose_sshift(c, p, sppCount);
   int rc = ensure_tiles(c, p, sshift);
   if (rc != RT_OK) return rc;
   rtk::RenderArgs A;
