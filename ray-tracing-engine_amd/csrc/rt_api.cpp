@@ -490,11 +490,17 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   S.n_photons = 0;
   S.invBoxScale = 1.f / c->bvh.boxScale;
   S.originBound = c->bvh.originBound;
-  // descent early-exit threshold (Trav::round); measured C2 / C4 / C5 Grays/s:
-  // 0 (off) 12.8 / 10.7 / 3.28, 8: 13.9 / - / -, 16: 13.7 / 12.0 / 4.00, 32: 13.0 / - / 4.02
-  S.leafT = getenv("RT_LEAFT") ? atoi(getenv("RT_LEAFT")) : 12;
+  // Pool thresholds (Trav::round's descent early exit, the steal and refill levels).  Two scene
+  // classes, as for the samples-of-a-pixel-per-wave rule: trees the caches hold (<= 65,536 nodes)
+  // are issue-bound and want long descents (12 / 8 / 24: C2 50.5 ms; 16 or 24 lanes cost 0.2-1 %);
+  // beyond that every step waits on the vector L1, and leaving the descent with up to 24 lanes still
+  // in it plus refilling at 32 hands out work sooner (C5 328.5 -> 317.4 ms, C5x8 55.0 -> 52.4 ms;
+  // profiles/r03_pool_thresholds.txt).
+  const bool bigTree = S.n_nodes > 65536;
+  S.leafT = getenv("RT_LEAFT") ? atoi(getenv("RT_LEAFT")) : bigTree ? 32 : 12;
+  S.leafMul = getenv("RT_LEAFMUL") ? atoi(getenv("RT_LEAFMUL")) : bigTree ? 32 : 22;
   S.stealT = getenv("RT_STEALT") ? atoi(getenv("RT_STEALT")) : 8;
-  S.refillT = getenv("RT_REFILLT") ? atoi(getenv("RT_REFILLT")) : 24;  // measured C2: 1 -> 15.9, 8 -> 16.0, 16 -> 16.1, 32 -> 16.2 Grays/s
+  S.refillT = getenv("RT_REFILLT") ? atoi(getenv("RT_REFILLT")) : bigTree ? 32 : 24;
   S.phPos = S.phDir = nullptr;
   S.topK = 0, S.ssRows = 0, S.ssOvRows = 0, S.ssOver = nullptr;
   S.cam = sc->camera;

@@ -272,7 +272,8 @@ struct Trav {
   template <bool STATS>
   RT_DEV void round(const DevScene& S, LaneStats& st) {
     const int live0 = __popcll(wave_ballot(cur != TERM));
-    const int exitBelow = min((int)S.leafT, (live0 + 2) / 3);
+    // (at least 1: the loop below leaves when FEWER lanes than this descend, so 0 would never leave)
+    const int exitBelow = max(1, min((int)S.leafT, (live0 * (int)S.leafMul) >> 6));
     uint32_t statWait = 0, statIdle = 0;
     if (STATS) statWait = (uint32_t)__popcll(wave_ballot(cur < 0 && cur != TERM)), statIdle = (uint32_t)__popcll(wave_ballot(cur == TERM));
     PHC(PH_N_ROUNDS);
@@ -363,7 +364,7 @@ struct Trav {
       // sit out one leaf phase (masked) instead of making everyone else wait for them
       // (only when the lanes that would otherwise wait clearly outnumber them: in the
       // tail of a pool, with a handful of live rays, a round must not shrink to one step)
-      // (desc < leafT and 3 * desc < live0, folded into one threshold)
+      // (desc < leafT and desc < live0 * leafMul / 64, folded into one threshold)
       }
      }
       inner = __builtin_amdgcn_ballot_w64(cur >= 0);
