@@ -33,7 +33,7 @@ struct Box {
 
 struct Prim {
   Box box;
-  float c[3];
+  float c[4];  // centroid; [3] = the SIZE key, -log2(longest box edge): a fourth "axis" to sweep or bin along
   uint32_t id;
 };
 
@@ -70,6 +70,21 @@ struct Builder {
     Box cb;
     cb.reset();
     for (uint32_t i = b; i < e; ++i) cb.grow(prims[i].c);
+    // The size axis: candidates "the k largest primitives | the rest".  A wall quad among a mesh's triangles has its
+    // centroid somewhere in the middle of the room, and every centroid split leaves it in a box with half the mesh;
+    // sorted by size it comes off first (the device builder's size classes, bvh_gpu.hip, had found the same thing).
+    // Node visits per ray / frame: C2 8.64 -> 7.80 / 50.1 -> 47.4 ms, C4 10.12 -> 8.55 / 937 -> 895 ms.  Greedy SAH is
+    // not monotone in its candidate set: taken whenever it is cheapest, the size cut costs the 1 M-triangle lattice
+    // 2.7 % (3.47 -> 3.57 triangle tests per ray) — so it has to beat the best centroid cut by a factor (1.5: the
+    // wall-against-mesh cuts are that decisive; 1.2 and 1.5 give the same C2 / C4 trees, 310 / 312 / 311 ms on C5
+    // for off / 1.2 / 1.5; profiles/r03_size_axis_ab.txt).  RT_BVH_SIZEAXIS: bit 0 swept ranges, bit 1 binned ranges.
+    static const int sizeAxisMode = getenv("RT_BVH_SIZEAXIS") ? atoi(getenv("RT_BVH_SIZEAXIS")) : 3;
+    static const float sizeBias = getenv("RT_BVH_SIZEBIAS") ? (float)atof(getenv("RT_BVH_SIZEBIAS")) : 1.5f;
+    const bool sizeAxis = (sizeAxisMode & (n <= kSweepMax ? 1 : 2)) != 0;
+    const int nAxes = sizeAxis ? 4 : 3;
+    float sLo = std::numeric_limits<float>::infinity(), sHi = -sLo;
+    if (sizeAxis)
+      for (uint32_t i = b; i < e; ++i) sLo = std::min(sLo, prims[i].c[3]), sHi = std::max(sHi, prims[i].c[3]);
     int axisOrder[3] = {0, 1, 2};
     std::sort(axisOrder, axisOrder + 3, [&](int x, int y) { return cb.hi[x] - cb.lo[x] > cb.hi[y] - cb.lo[y]; });
     auto medianSplit = [&]() {
@@ -90,7 +105,8 @@ struct Builder {
       int bestAx = -1;
       uint32_t bestPos = 0;
       std::vector<float> rightArea(n);
-      for (int ax = 0; ax < 3; ++ax) {
+      for (int ax = 0; ax < nAxes; ++ax) {
+        if (ax == 3 && !(sHi > sLo)) continue;
         std::sort(prims.begin() + b, prims.begin() + e,
                   [ax](const Prim& p, const Prim& q) { return p.c[ax] < q.c[ax] || (p.c[ax] == q.c[ax] && p.id < q.id); });
         Box acc;
@@ -102,8 +118,9 @@ struct Builder {
         acc.reset();
         for (uint32_t i = 1; i < n; ++i) {
           acc.grow(prims[b + i - 1].box);
-          const float cost = acc.halfArea() * std::ceil(i / static_cast<float>(leafMax)) +
-                             rightArea[i] * std::ceil((n - i) / static_cast<float>(leafMax));
+          float cost = acc.halfArea() * std::ceil(i / static_cast<float>(leafMax)) +
+                       rightArea[i] * std::ceil((n - i) / static_cast<float>(leafMax));
+          if (ax == 3) cost *= sizeBias;
           if (cost < bestCostS && i <= maxSide && n - i <= maxSide) bestCostS = cost, bestAx = ax, bestPos = i;
         }
       }
@@ -126,15 +143,16 @@ struct Builder {
     const int NB = (int)n < nbSplit ? 16 : nbEnv >= 2 && nbEnv <= NBMAX ? nbEnv : 64;
     float bestCost = std::numeric_limits<float>::infinity();
     int bestAxis = -1, bestBin = -1;
-    for (int ax = 0; ax < 3; ++ax) {
-      const float ext = cb.hi[ax] - cb.lo[ax];
+    for (int ax = 0; ax < nAxes; ++ax) {
+      const float axLo = ax < 3 ? cb.lo[ax] : sLo;
+      const float ext = ax < 3 ? cb.hi[ax] - cb.lo[ax] : sHi - sLo;
       if (!(ext > 0.f)) continue;
       Box bb[NBMAX];
       uint32_t cnt[NBMAX] = {0};
       for (int k = 0; k < NB; ++k) bb[k].reset();
       const float scale = NB / ext;
       for (uint32_t i = b; i < e; ++i) {
-        int k = std::min(NB - 1, std::max(0, static_cast<int>((prims[i].c[ax] - cb.lo[ax]) * scale)));
+        int k = std::min(NB - 1, std::max(0, static_cast<int>((prims[i].c[ax] - axLo) * scale)));
         bb[k].grow(prims[i].box), ++cnt[k];
       }
       float rightArea[NBMAX];
@@ -153,12 +171,13 @@ struct Builder {
         // leaves hold up to leafMax triangles: cost in units of leaf fetches
         float cost = acc.halfArea() * std::ceil(c / static_cast<float>(leafMax)) +
                      rightArea[k + 1] * std::ceil(rightCnt[k + 1] / static_cast<float>(leafMax));
+        if (ax == 3) cost *= sizeBias;
         if (cost < bestCost) bestCost = cost, bestAxis = ax, bestBin = k;
       }
     }
     if (bestAxis < 0) return medianSplit();
-    const float ext = cb.hi[bestAxis] - cb.lo[bestAxis];
-    const float scale = NB / ext, lo = cb.lo[bestAxis];
+    const float ext = bestAxis < 3 ? cb.hi[bestAxis] - cb.lo[bestAxis] : sHi - sLo;
+    const float scale = NB / ext, lo = bestAxis < 3 ? cb.lo[bestAxis] : sLo;
     const int ax = bestAxis, bin = bestBin;
     auto mid = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim& p) {
       int k = std::min(NB - 1, std::max(0, static_cast<int>((p.c[ax] - lo) * scale)));
@@ -731,6 +750,7 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
         p.box.grow(q);
       }
       for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+      p.c[3] = -std::log2(std::max({p.box.hi[0] - p.box.lo[0], p.box.hi[1] - p.box.lo[1], p.box.hi[2] - p.box.lo[2], 1e-30f}));
       out.trisRef[t] = makeRec(sc, t, m);
     }
   }

@@ -58,6 +58,50 @@ static float run(const uint4* table, uint32_t recQuads, uint32_t nrec, uint32_t 
   return ms;
 }
 
+
+// Cooperative fetch: the G = REQ lanes of a group fetch each other's records together — instruction j loads the record
+// of the group's lane j, every lane one 16-B quad of it (adjacent lanes, adjacent quads of one record).  The same bytes
+// per lane as k_chase<REQ, 1>, but every instruction touches 64 / G cache lines instead of 64: does the vector L1 spend
+// its tag lookups per LANE or per distinct LINE of neighbouring lanes?
+template <int G>
+__global__ __launch_bounds__(1024) void k_chase_coop(const uint4* __restrict__ table, uint32_t nrec, uint32_t steps, uint32_t* __restrict__ sink) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u, sub = lane % G, base = lane - sub;
+  uint32_t cur = (uint32_t)(((uint64_t)(gid * 2654435761u) * 2246822519u) % nrec);
+  uint32_t acc = 0;
+  for (uint32_t s = 0; s < steps; ++s) {
+    uint4 v[G];
+    for (int j = 0; j < G; ++j) {
+      const uint32_t rec = (uint32_t)__shfl((int)cur, (int)(base + j));
+      v[j] = table[(size_t)rec * G + sub];
+    }
+    uint32_t next = 0;
+    for (int j = 0; j < G; ++j) {
+      const uint32_t w = (uint32_t)__shfl((int)v[j].x, (int)base);  // word 0 of quad 0 of lane j's record
+      next = sub == (uint32_t)j ? w : next;
+      acc += v[j].y ^ v[j].w;
+    }
+    cur = next;
+  }
+  if (acc == 0x12345678u) sink[gid] = acc;
+  if (gid == 0) sink[0] = cur;
+}
+
+template <int G>
+static float run_coop(const uint4* table, uint32_t nrec, uint32_t steps, uint32_t* sink, int cus, int waves) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  hipLaunchKernelGGL((k_chase_coop<G>), dim3(cus), dim3(64 * waves), 0, nullptr, table, nrec, 8u, sink);  // warm
+  CK(hipEventRecord(a));
+  hipLaunchKernelGGL((k_chase_coop<G>), dim3(cus), dim3(64 * waves), 0, nullptr, table, nrec, steps, sink);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms;
+}
+
 // `gather_bench one <table KB> <record bytes>`: one configuration (2 requests per record, one chain, 16 waves per CU) and
 // nothing else — what a rocprofv3 --pmc FETCH_SIZE pass is pointed at to see the HBM-side bytes a random record costs.
 static int one(size_t tableKB, uint32_t recBytes);
@@ -110,6 +154,17 @@ int main(int argc, char** argv) {
                  first ? "" : ",\n", tableKB, recBytes, waves, req, ch, coh, ms, stepCycles, laneReqPerClk, recPerSec / 1e9,
                  recPerSec * req * 16 / 1e9);
           first = false;
+        }
+        {
+          // the cooperative fetch of the same records (REQ = lanes per group = quads per record)
+          const uint32_t steps = tableMB >= 128 ? 512u : 2048u;
+          const float ms = recQuads == 2 ? run_coop<2>(d, nrec, steps, sink, cus, waves) : run_coop<4>(d, nrec, steps, sink, cus, waves);
+          const double cyc = ms * 1e-3 * ghz * 1e9;
+          const double recPerSec = (double)cus * waves * 64 * steps / (ms * 1e-3);
+          printf(",\n{\"table_kb\": %zu, \"rec_bytes\": %u, \"waves_per_cu\": %d, \"req_per_rec\": %u, \"chains\": 1, \"coherent\": 0, \"cooperative_lanes\": %u, "
+                 "\"ms\": %.3f, \"step_cycles\": %.0f, \"lane_req_per_clk_per_cu\": %.3f, \"grec_per_s\": %.1f, \"gbs\": %.0f}",
+                 tableKB, recBytes, waves, recQuads, recQuads, ms, cyc / steps, (double)waves * 64 * recQuads * steps / cyc, recPerSec / 1e9,
+                 recPerSec * recBytes / 1e9);
         }
       }
       CK(hipFree(d));
