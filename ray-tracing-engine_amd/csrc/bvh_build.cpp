@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -393,6 +394,187 @@ struct Rotator {
       out.push_back(n);
     }
     nodes.swap(out);
+  }
+};
+
+
+// ---------------------------------------------------------------- subtree reinsertion
+// The second post-pass (after Bittner, Hapala, Havran: "Fast insertion-based optimization of bounding
+// volume hierarchies", 2013, restated): a subtree L is taken out of the tree (its parent goes with it, its
+// sibling moves up) and put back at the position X — any node of the tree — where "a new node over X and L"
+// adds the least surface area to the tree: area(X u L) for the new node plus what the ancestors of X grow
+// by.  A branch-and-bound search from the root finds X (the induced growth only increases on the way down,
+// so a branch is cut as soon as it alone exceeds the best total found).  Rotations only see moves between
+// a node and its grandchildren; this one moves a subtree across the whole tree, which is what a top-down
+// SAH build cannot undo: a split made with the information of its level only.  The depth cap is enforced
+// (a position that would push a leaf below it is not a candidate), the leaves themselves never change, and
+// the procedure is deterministic (fixed order, no threads).
+struct Reinserter {
+  struct Item {
+    Box box;
+    int32_t parent, child[2];  // child: item index; -1 on a leaf
+    int32_t leafRef;           // the leaf's code (negative); 0 on an inner node
+    uint8_t height;            // max leaf depth below (a leaf: 0)
+  };
+  std::vector<Item> it;
+  int depthCap;
+  uint32_t nInner = 0;
+  uint64_t moves = 0;
+
+  void load(const std::vector<Node>& nodes) {
+    nInner = (uint32_t)nodes.size();
+    it.assign(nInner, Item{});
+    it.reserve(2 * (size_t)nInner + 1);
+    for (uint32_t i = 0; i < nInner; ++i) it[i].leafRef = 0, it[i].parent = -1;
+    for (uint32_t i = 0; i < nInner; ++i)
+      for (int k = 0; k < 2; ++k) {
+        const int32_t ref = nodes[i].child[k];
+        const Box b = Rotator::childBox(nodes[i], k);
+        if (ref >= 0) {
+          it[ref].box = b, it[ref].parent = (int32_t)i, it[i].child[k] = ref;
+        } else {
+          Item l{};
+          l.box = b, l.parent = (int32_t)i, l.child[0] = l.child[1] = -1, l.leafRef = ref, l.height = 0;
+          it[i].child[k] = (int32_t)it.size();
+          it.push_back(l);
+        }
+      }
+    it[0].box = it[it[0].child[0]].box;
+    it[0].box.grow(it[it[0].child[1]].box);
+    // heights, children before parents (explicit post-order)
+    std::vector<std::pair<int32_t, int>> st{{0, 0}};
+    while (!st.empty()) {
+      auto& [i, phase] = st.back();
+      if (it[i].child[0] < 0) {
+        st.pop_back();
+        continue;
+      }
+      if (phase < 2) {
+        const int32_t c = it[i].child[phase++];
+        st.push_back({c, 0});
+      } else {
+        it[i].height = (uint8_t)(1 + std::max(it[it[i].child[0]].height, it[it[i].child[1]].height));
+        st.pop_back();
+      }
+    }
+  }
+
+  void store(std::vector<Node>& nodes) const {
+    for (uint32_t i = 0; i < nInner; ++i)
+      for (int k = 0; k < 2; ++k) {
+        const Item& c = it[it[i].child[k]];
+        Rotator::setChild(nodes[i], k, c.child[0] < 0 ? c.leafRef : it[i].child[k], c.box);
+      }
+  }
+
+  void refit(int32_t g) {
+    for (; g >= 0; g = it[g].parent) {
+      Item& G = it[g];
+      Box b = it[G.child[0]].box;
+      b.grow(it[G.child[1]].box);
+      const uint8_t h = (uint8_t)(1 + std::max(it[G.child[0]].height, it[G.child[1]].height));
+      bool same = h == G.height;
+      for (int a = 0; a < 3 && same; ++a) same = b.lo[a] == G.box.lo[a] && b.hi[a] == G.box.hi[a];
+      if (same) break;
+      G.box = b, G.height = h;
+    }
+  }
+
+  double innerArea() const {
+    double s = 0;
+    for (uint32_t i = 0; i < nInner; ++i) s += it[i].box.halfArea();
+    return s;
+  }
+
+  struct Cand {
+    float bound;  // induced + area(L): no position below this node can cost less
+    float induced;
+    int32_t item;
+    int depth;
+    bool operator<(const Cand& o) const { return bound > o.bound || (bound == o.bound && item > o.item); }  // min-heap
+  };
+  std::vector<Cand> heap;
+
+  // true if L was moved
+  bool reinsert(int32_t l) {
+    const int32_t p = it[l].parent;
+    if (p <= 0) return false;  // the root's children stay (the root is never re-created)
+    const int32_t g = it[p].parent;
+    const int sl = it[p].child[1] == l ? 1 : 0;
+    const int32_t s = it[p].child[1 - sl];
+    const int sp = it[g].child[1] == p ? 1 : 0;
+    // take L (and P) out
+    it[g].child[sp] = s, it[s].parent = g;
+    refit(g);
+    const Box lb = it[l].box;
+    const float la = lb.halfArea();
+    const int lh = it[l].height;
+    float best = std::numeric_limits<float>::infinity();
+    int32_t bestX = -1;
+    heap.clear();
+    heap.push_back(Cand{la, 0.f, it[0].child[0], 1});
+    std::push_heap(heap.begin(), heap.end());
+    heap.push_back(Cand{la, 0.f, it[0].child[1], 1});
+    std::push_heap(heap.begin(), heap.end());
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end());
+      const Cand c = heap.back();
+      heap.pop_back();
+      if (c.bound >= best) break;
+      const Item& X = it[c.item];
+      if (c.depth + 1 + lh > depthCap) continue;  // L itself would end up too deep here and anywhere below
+      Box u = X.box;
+      u.grow(lb);
+      const float direct = u.halfArea();
+      const float total = c.induced + direct;
+      if (total < best && c.depth + 1 + (int)X.height <= depthCap) best = total, bestX = c.item;
+      if (X.child[0] >= 0) {
+        const float ind = c.induced + direct - X.box.halfArea();
+        if (ind + la < best) {
+          heap.push_back(Cand{ind + la, ind, X.child[0], c.depth + 1});
+          std::push_heap(heap.begin(), heap.end());
+          heap.push_back(Cand{ind + la, ind, X.child[1], c.depth + 1});
+          std::push_heap(heap.begin(), heap.end());
+        }
+      }
+    }
+    // the old position, priced the same way: a move must be a strict gain (no wandering between equal positions)
+    {
+      Box u = it[s].box;
+      u.grow(lb);
+      float costS = u.halfArea();
+      for (int32_t a = it[s].parent; a > 0; a = it[a].parent) {
+        Box w = it[a].box;
+        w.grow(lb);
+        costS += w.halfArea() - it[a].box.halfArea();
+      }
+      if (bestX < 0 || !(best < costS * (1.f - 1e-6f))) bestX = s;
+    }
+    // put P back over (X, L)
+    const int32_t xp = it[bestX].parent;
+    const int sx = it[xp].child[1] == bestX ? 1 : 0;
+    it[xp].child[sx] = p, it[p].parent = xp;
+    it[p].child[0] = bestX, it[p].child[1] = l;
+    it[bestX].parent = p, it[l].parent = p;
+    it[p].box = it[bestX].box;
+    it[p].box.grow(lb);
+    it[p].height = (uint8_t)(1 + std::max(it[bestX].height, it[l].height));
+    refit(xp);
+    if (bestX != s) ++moves;
+    return bestX != s;
+  }
+
+  // one pass: every subtree whose box is at least `minFrac` of the root's, largest first
+  void pass(float minFrac) {
+    std::vector<std::pair<float, int32_t>> order;
+    const float rootA = it[0].box.halfArea();
+    for (int32_t i = 1; i < (int32_t)it.size(); ++i)
+      if (it[i].parent > 0) {
+        const float a = it[it[i].parent].box.halfArea();  // what a badly placed subtree inflates is its parent
+        if (a >= minFrac * rootA) order.push_back({a, i});
+      }
+    std::sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+    for (const auto& o : order) reinsert(o.second);
   }
 };
 
@@ -791,6 +973,25 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   }
   out.nodes.swap(top.nodes);
   out.maxDepth = top.maxDepth;
+  {
+    // reinsertion passes (RT_BVH_REINSERT overrides; 0 = off)
+    const char* e = getenv("RT_BVH_REINSERT");
+    const int passes = e ? atoi(e) : 0;
+    if (passes > 0 && out.nodes.size() > 2) {
+      Reinserter R;
+      R.depthCap = B.depthCap;
+      R.load(out.nodes);
+      const double a0 = R.innerArea();
+      for (int p = 0; p < passes; ++p) {
+        const uint64_t before = R.moves;
+        R.pass(0.f);
+        if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "reinsertion pass %d: %llu moves, inner area %.6g -> %.6g\n", p, (unsigned long long)(R.moves - before), a0, R.innerArea());
+        if (R.moves == before) break;
+      }
+      R.store(out.nodes);
+      out.maxDepth = R.it[0].height;
+    }
+  }
   {
     // rotation passes (RT_BVH_ROT overrides; 0 = off).  Measured with 4: nodes/ray 9.06 -> 8.71
     // on C2 (+1.9 %), 38.1 -> 37.2 on C5 (+1.1 %); SAH cost -3 % / -0.3 % / -2.4 % (1.2 k /

@@ -39,3 +39,18 @@ def test_wide_collapse_leaf_sizes_and_tiny_scenes():
                              a["materials"][:1], a["lights"], a["camera"])
         r = pyrt.bvh_wide_check_host(sc, 0, 0)
         assert r["wide_nodes"] >= 1 and r["stack_need"] >= 1
+
+
+@pytest.mark.parametrize("kind", ["lowres", "hires"])
+def test_reinsertion_passes_keep_the_tree_valid_and_lower_its_surface_area(kind, monkeypatch):
+    """bvh_build.cpp Reinserter (opt-in, RT_BVH_REINSERT=passes): subtrees are moved across the tree where that lowers
+    the summed surface area.  The structure check must still pass (every triangle once, boxes contain their padded
+    geometry, depth within the cap) and the surface-area estimate of node visits must drop.  (It stays opt-in: the
+    estimate drops 6 % / 3 % and the MEASURED node visits of the renderer's rays rise 1 % / 1.6 %: DESIGN.md section 3.)"""
+    s = pyrt.Scene(kind, 32, 32)
+    monkeypatch.setenv("RT_BVH_ROT", "0")
+    base = pyrt.bvh_wide_check_host(s, 0, 30)
+    monkeypatch.setenv("RT_BVH_REINSERT", "3")
+    opt = pyrt.bvh_wide_check_host(s, 0, 30)
+    assert opt["binary_nodes"] == base["binary_nodes"] and opt["binary_depth"] <= base["binary_depth"] + 3
+    assert opt["visits2"] < 0.99 * base["visits2"]

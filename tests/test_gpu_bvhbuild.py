@@ -94,20 +94,20 @@ def test_frames_on_device_built_tree_vs_oracle(kind, w, h, spp):
 
 
 def test_device_builder_variants_are_exact(tmp_path):
-    """The device builder's other configurations (environment knobs, read once per process): Morton cuts all the
+    """The builders' other configurations (environment knobs, read once per process): Morton cuts all the
     way down (RT_BVH_GPU_SUB=0, round 2's tree), exact subtrees of <= 64 triangles, and the binned-SAH top
     (RT_BVH_GPU_TOP=binned: k_top_split).  Every one must give the exhaustive loop's hits and the default tree's frame."""
     import subprocess
     import sys
     script = tmp_path / "v.py"
     script.write_text('''
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, sys.argv[1] + "/ray-tracing-engine_amd"); sys.path.insert(0, sys.argv[1] + "/tests")
 import pyrt
 from raybatch import ray_batch
 out = {}
 for kind, w, spp, n in (("lowres", 64, 4, 60000), ("hires", 48, 3, 60000), ("stress", 32, 2, 30000)):
-    s = pyrt.Scene(kind, w, w); ctx = pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE)
+    s = pyrt.Scene(kind, w, w); ctx = pyrt.Context(s, bvh_builder=pyrt.BVH_HOST if os.environ.get("RT_TEST_HOST_BUILDER") else pyrt.BVH_DEVICE)
     rays = ray_batch(s, n, 11)
     got, want = ctx.trace(rays, pyrt.ACCEL_BVH), ctx.trace(rays, pyrt.ACCEL_BRUTE)
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), kind
@@ -120,7 +120,13 @@ np.savez(sys.argv[2], **out)
 ''')
     runs = {}
     for name, env in (("default", {}), ("morton_all_the_way", {"RT_BVH_GPU_SUB": "0"}), ("subtrees_64", {"RT_BVH_GPU_SUB": "64"}),
-                      ("binned_top", {"RT_BVH_GPU_TOP": "binned"}), ("binned_top_64_bins", {"RT_BVH_GPU_TOP": "binned", "RT_BVH_GPU_BINS": "64"})):
+                      ("binned_top", {"RT_BVH_GPU_TOP": "binned"}), ("binned_top_64_bins", {"RT_BVH_GPU_TOP": "binned", "RT_BVH_GPU_BINS": "64"}),
+                      # ... and the host builder's: its default, without the size axis, with an unbiased size axis, with
+                      # reinsertion passes (with and without the rotations behind them)
+                      ("host", {"RT_TEST_HOST_BUILDER": "1"}), ("host_no_size_axis", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_SIZEAXIS": "0"}),
+                      ("host_size_axis_unbiased", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_SIZEBIAS": "1"}),
+                      ("host_reinsertion", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_REINSERT": "3"}),
+                      ("host_reinsertion_no_rotations", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_REINSERT": "3", "RT_BVH_ROT": "0"})):
         out = tmp_path / (name + ".npz")
         r = subprocess.run([sys.executable, str(script), pyrt.ROOT, str(out)], env=dict(os.environ, **env), capture_output=True,
                            text=True, timeout=600)
