@@ -116,7 +116,7 @@ def pmc_measure(args, rank=0, world=1):
             if args.spp:
                 cmd += ["--spp", str(args.spp)]
             # the child must run THIS run's kernel configuration (integrator, samples per wave, leaf size)
-            cmd += ["--integrator", args.integrator, "--lpp", str(args.lpp), "--leaf", str(args.leaf),
+            cmd += ["--integrator", args.integrator, "--lpp", str(args.lpp), "--leaf", str(args.leaf), "--tune-probes", str(args.tune_probes),
                     "--pmc-rank", str(rank), "--pmc-world", str(world)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             rows = {}
@@ -144,11 +144,23 @@ def pmc_child(args):
     spp = args.spp or spp
     scene = pyrt.Scene(kind, w, h)
     ctx = pyrt.Context(scene, device=0, bvh_leaf_max=args.leaf)
+    tune_tree(ctx, pyrt, args, mode, nph)  # (the same deterministic tuning as the timed run's)
     params = build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, args.pmc_rank, args.pmc_world)
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
     ctx.render_device(params, accum.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     ctx.close()
+
+
+def tune_tree(ctx, pyrt, args, mode, nph):
+    """--tune-probes N: rt_bvh_tune on 128x128x1 probe frames of this workload's camera and integrator."""
+    if not args.tune_probes or nph or args.accel != "bvh":
+        return None
+    probe = pyrt.make_params(128, 128, 1, mode=mode, seed=7)
+    rep = ctx.tune(probe, 600.0, args.tune_probes)
+    return {"probes": rep.probes, "changes_kept": rep.accepted, "probe_cost_before": rep.cost_before,
+            "probe_cost_after": rep.cost_after, "seconds": rep.seconds,
+            "note": "rt_bvh_tune: subtree moves / child slot orders kept only where a probe frame's node visits + 1.5 x triangle tests fell; same image"}
 
 
 # ----------------------------------------------------------------------------- CPU baseline
@@ -263,6 +275,9 @@ def main():
     ap.add_argument("--accel", default="bvh", choices=["bvh", "brute"])
     ap.add_argument("--leaf", type=int, default=0, help="BVH leaf size override (debug)")
     ap.add_argument("--lpp", type=int, default=0, help="samples of a pixel per wave override (debug)")
+    ap.add_argument("--tune-probes", type=int, default=0,
+                    help="measured-cost BVH tuning before the frames (rt_bvh_tune): this many probe frames of the workload's camera "
+                         "at 128x128x1 (deterministic: a probe count, not a time limit); 0 = off (the default)")
     ap.add_argument("--integrator", default="fused", choices=["fused", "wavefront"],
                     help="wavefront = the opt-in queue-based integrator (same image; DESIGN.md section 8)")
     args = ap.parse_args()
@@ -307,6 +322,7 @@ def main():
         spp = args.spp
     scene = pyrt.Scene(kind, w, h)
     ctx = pyrt.Context(scene, device=local, bvh_leaf_max=args.leaf)  # raises if the HIP library / a gfx950 device is missing
+    tuned = tune_tree(ctx, pyrt, args, mode, nph)
     params = build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, rank, world)
 
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
@@ -460,6 +476,8 @@ def main():
                        "knn_queries_per_frame": tot[5]},
             "roofline": roof,
         }
+        if tuned:
+            res["config"]["bvh_tune"] = tuned
         if not args.no_cpu_baseline:
             # (rank 0 only, after the timed region; at N > 1 the other ranks have left the job by now)
             rdist.shutdown()

@@ -281,6 +281,25 @@ int rt_bvh_build_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t th
  * random ray, binary / wide.  (No reference counterpart: BVH.h is dead code there.) */
 int rt_bvh_wide_check_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t stack_budget, uint32_t* out8,
                            double* est2);
+/* Measured-cost tuning of the host-built BVH (no counterpart in the reference, whose rayTrace is the exhaustive
+ * loop of RayTracer.h:27-53; this only changes HOW FAST the same hits are found).  Every tree over the same leaves
+ * returns the same hits, so a probe frame traces exactly the same rays whatever the tree and its counters are a
+ * deterministic cost of the tree for the rays of THIS scene, camera and integrator.  rt_bvh_tune renders `probe`
+ * (a small frame: e.g. 128x128, 1-2 spp, the mode of the real render) once per proposed change — a subtree moved to
+ * another place in the tree, the two children of a node in the other slot order — and keeps a change only if
+ * nodes_visited + 1.5 * tris_tested fell.  Stops after `budget_seconds`, after `max_probes` probe frames (0 = no limit;
+ * the counters are deterministic, so a probe limit — unlike a time limit — gives the same tree on every run) or when a
+ * whole pass finds nothing; a second
+ * probe with another seed referees the result (a tuned tree that is not better on it is dropped: accepted = 0).  Images
+ * are unchanged by construction (and tested).  Needs a host-built binary tree (RT_ERR_STATE otherwise); must not run
+ * concurrently with a launch on the same context. */
+typedef struct rt_tune_report {
+  uint32_t probes, accepted;
+  double cost_before, cost_after; /* nodes_visited + 1.5 * tris_tested of the probe frame */
+  double seconds;
+  uint64_t reserved[4];
+} rt_tune_report;
+int rt_bvh_tune(rt_ctx* ctx, const rt_params* probe, double budget_seconds, uint32_t max_probes, rt_tune_report* out);
 /* Device-time bookkeeping: every rt_render_device launch is bracketed by a HIP
  * event pair on its stream.  reset() forgets them; collect() synchronises the
  * device and returns the summed kernel time of the launches since reset

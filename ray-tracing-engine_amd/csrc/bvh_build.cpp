@@ -2,6 +2,7 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -495,22 +496,53 @@ struct Reinserter {
   };
   std::vector<Cand> heap;
 
-  // true if L was moved
-  bool reinsert(int32_t l) {
-    const int32_t p = it[l].parent;
-    if (p <= 0) return false;  // the root's children stay (the root is never re-created)
-    const int32_t g = it[p].parent;
+  // Takes L and its parent P out (the sibling S moves up); returns S.  L must not be a child of the root.
+  int32_t takeOut(int32_t l) {
+    const int32_t p = it[l].parent, g = it[p].parent;
     const int sl = it[p].child[1] == l ? 1 : 0;
     const int32_t s = it[p].child[1 - sl];
     const int sp = it[g].child[1] == p ? 1 : 0;
-    // take L (and P) out
     it[g].child[sp] = s, it[s].parent = g;
     refit(g);
+    return s;
+  }
+  // Puts P (L's detached parent) back as a new node over (X, L).
+  void putBack(int32_t l, int32_t x) {
+    const int32_t p = it[l].parent;
+    const int32_t xp = it[x].parent;
+    const int sx = it[xp].child[1] == x ? 1 : 0;
+    it[xp].child[sx] = p, it[p].parent = xp;
+    it[p].child[0] = x, it[p].child[1] = l;
+    it[x].parent = p, it[l].parent = p;
+    it[p].box = it[x].box;
+    it[p].box.grow(it[l].box);
+    it[p].height = (uint8_t)(1 + std::max(it[x].height, it[l].height));
+    refit(xp);
+  }
+  // what "a new node over (X, L)" adds to the tree's surface area: the new node + the growth of X's ancestors
+  float costAt(int32_t x, const Box& lb) const {
+    Box u = it[x].box;
+    u.grow(lb);
+    float c = u.halfArea();
+    for (int32_t a = it[x].parent; a > 0; a = it[a].parent) {
+      Box w = it[a].box;
+      w.grow(lb);
+      c += w.halfArea() - it[a].box.halfArea();
+    }
+    return c;
+  }
+  // The K best positions for the (taken-out) subtree L by added surface area, `exclude` not being a candidate
+  // (best first; fewer if fewer are admissible).
+  struct Pos {
+    float cost;
+    int32_t item;
+  };
+  void searchK(int32_t l, int32_t exclude, int K, std::vector<Pos>& out) {
     const Box lb = it[l].box;
     const float la = lb.halfArea();
     const int lh = it[l].height;
-    float best = std::numeric_limits<float>::infinity();
-    int32_t bestX = -1;
+    out.clear();
+    auto worst = [&] { return (int)out.size() < K ? std::numeric_limits<float>::infinity() : out.back().cost; };
     heap.clear();
     heap.push_back(Cand{la, 0.f, it[0].child[0], 1});
     std::push_heap(heap.begin(), heap.end());
@@ -520,17 +552,22 @@ struct Reinserter {
       std::pop_heap(heap.begin(), heap.end());
       const Cand c = heap.back();
       heap.pop_back();
-      if (c.bound >= best) break;
+      if (c.bound >= worst()) break;
       const Item& X = it[c.item];
       if (c.depth + 1 + lh > depthCap) continue;  // L itself would end up too deep here and anywhere below
       Box u = X.box;
       u.grow(lb);
       const float direct = u.halfArea();
       const float total = c.induced + direct;
-      if (total < best && c.depth + 1 + (int)X.height <= depthCap) best = total, bestX = c.item;
+      if (total < worst() && c.item != exclude && c.depth + 1 + (int)X.height <= depthCap) {
+        if ((int)out.size() == K) out.pop_back();
+        size_t at = out.size();
+        out.push_back(Pos{total, c.item});
+        while (at > 0 && (out[at - 1].cost > total || (out[at - 1].cost == total && out[at - 1].item > c.item))) std::swap(out[at - 1], out[at]), --at;
+      }
       if (X.child[0] >= 0) {
         const float ind = c.induced + direct - X.box.halfArea();
-        if (ind + la < best) {
+        if (ind + la < worst()) {
           heap.push_back(Cand{ind + la, ind, X.child[0], c.depth + 1});
           std::push_heap(heap.begin(), heap.end());
           heap.push_back(Cand{ind + la, ind, X.child[1], c.depth + 1});
@@ -538,30 +575,25 @@ struct Reinserter {
         }
       }
     }
+  }
+  int32_t search(int32_t l, int32_t exclude, float& bestOut) {
+    std::vector<Pos> one;
+    searchK(l, exclude, 1, one);
+    bestOut = one.empty() ? std::numeric_limits<float>::infinity() : one[0].cost;
+    return one.empty() ? -1 : one[0].item;
+  }
+
+  // true if L was moved
+  bool reinsert(int32_t l) {
+    if (it[l].parent <= 0) return false;  // the root's children stay (the root is never re-created)
+    const int32_t s = takeOut(l);
+    float best;
+    int32_t x = search(l, -1, best);
     // the old position, priced the same way: a move must be a strict gain (no wandering between equal positions)
-    {
-      Box u = it[s].box;
-      u.grow(lb);
-      float costS = u.halfArea();
-      for (int32_t a = it[s].parent; a > 0; a = it[a].parent) {
-        Box w = it[a].box;
-        w.grow(lb);
-        costS += w.halfArea() - it[a].box.halfArea();
-      }
-      if (bestX < 0 || !(best < costS * (1.f - 1e-6f))) bestX = s;
-    }
-    // put P back over (X, L)
-    const int32_t xp = it[bestX].parent;
-    const int sx = it[xp].child[1] == bestX ? 1 : 0;
-    it[xp].child[sx] = p, it[p].parent = xp;
-    it[p].child[0] = bestX, it[p].child[1] = l;
-    it[bestX].parent = p, it[l].parent = p;
-    it[p].box = it[bestX].box;
-    it[p].box.grow(lb);
-    it[p].height = (uint8_t)(1 + std::max(it[bestX].height, it[l].height));
-    refit(xp);
-    if (bestX != s) ++moves;
-    return bestX != s;
+    if (x < 0 || !(best < costAt(s, it[l].box) * (1.f - 1e-6f))) x = s;
+    putBack(l, x);
+    if (x != s) ++moves;
+    return x != s;
   }
 
   // one pass: every subtree whose box is at least `minFrac` of the root's, largest first
@@ -894,6 +926,148 @@ void collapse4(Built& b, uint32_t stackBudget) {
   b.visitCost2 = v2;
 }
 
+
+// Child 0 = the child with the SMALLER box: any-hit rays of the big-scene kernels enter it first (rt_kernels.hip
+// Trav::round); closest-hit traversal orders by entry distance and does not care.
+static void smallerChildFirst(std::vector<Node>& nodes) {
+  for (Node& n : nodes) {
+    Box b0, b1;
+    for (int a = 0; a < 3; ++a) b0.lo[a] = n.lo0[a], b0.hi[a] = n.hi0[a], b1.lo[a] = n.lo1[a], b1.hi[a] = n.hi1[a];
+    if (b1.halfArea() < b0.halfArea()) {
+      for (int a = 0; a < 3; ++a) std::swap(n.lo0[a], n.lo1[a]), std::swap(n.hi0[a], n.hi1[a]);
+      std::swap(n.child[0], n.child[1]);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------- measured-cost tuning
+// The surface-area heuristic prices uniformly distributed lines; the renderer's rays start on surfaces and half
+// of them aim at the lights, and beyond a few percent the estimate no longer predicts their node visits (the
+// reinsertion passes above: -6 % area, +1 % visits).  But the visits can be MEASURED: every tree over the same
+// leaves returns the same hits, so a probe frame traces exactly the same rays whatever the tree, and its counters
+// (node records fetched, triangles tested) are a deterministic cost of the tree for these rays.  tuneMeasured
+// proposes moves — a subtree to the position the area search likes best other than where it is; the two children
+// of a node in the other slot order (which child an any-hit ray enters first) — applies each, asks `measure`
+// for the cost of b.nodes, and keeps the move only if the cost fell.  Leaves never change; no leaf ends up deeper
+// than the deepest leaf of the tree as it came in (the traversal stacks were sized for it).
+TuneReport tuneMeasured(Built& b, const std::function<double()>& measure, double budgetSeconds, uint32_t maxProbes, int verbose) {
+  TuneReport rep{};
+  const auto t0 = std::chrono::steady_clock::now();
+  auto clock = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  // "elapsed" = either budget used up: seconds, or probe frames
+  auto elapsed = [&] { return (maxProbes && rep.probes >= maxProbes) ? budgetSeconds : clock(); };
+  if (b.nodes.size() < 3) return rep;
+  Reinserter R;
+  R.depthCap = (int)b.maxDepth;
+  R.load(b.nodes);
+  std::vector<uint8_t> flip(b.nodes.size(), 0);
+  auto publish = [&] {
+    R.store(b.nodes);
+    smallerChildFirst(b.nodes);
+    for (size_t i = 0; i < b.nodes.size(); ++i)
+      if (flip[i]) {
+        Node& n = b.nodes[i];
+        for (int a = 0; a < 3; ++a) std::swap(n.lo0[a], n.lo1[a]), std::swap(n.hi0[a], n.hi1[a]);
+        std::swap(n.child[0], n.child[1]);
+      }
+  };
+  publish();
+  double best = measure();
+  rep.cost0 = best, rep.probes = 1;
+  const float slack = getenv("RT_TUNE_SLACK") ? (float)atof(getenv("RT_TUNE_SLACK")) : 1.25f;
+  const int topK = getenv("RT_TUNE_K") ? std::max(1, atoi(getenv("RT_TUNE_K"))) : 1;
+  std::vector<Reinserter::Pos> cand;
+  double gainMoves = 0, gainFlips = 0;
+  uint32_t nMoves = 0, nFlips = 0;
+  for (int pass = 0; pass < 64 && elapsed() < budgetSeconds; ++pass) {
+    uint32_t acceptedThisPass = 0;
+    // (a) subtree moves, largest parent first
+    std::vector<std::pair<float, int32_t>> order;
+    for (int32_t i = 1; i < (int32_t)R.it.size(); ++i)
+      if (R.it[i].parent > 0) order.push_back({R.it[R.it[i].parent].box.halfArea(), i});
+    std::sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+    for (const auto& o : order) {
+      if (elapsed() >= budgetSeconds) break;
+      const int32_t l = o.second;
+      if (R.it[l].parent <= 0) continue;
+      int32_t sOld = R.takeOut(l);
+      R.searchK(l, sOld, topK, cand);
+      const float limit = R.costAt(sOld, R.it[l].box) * slack;
+      R.putBack(l, sOld);
+      for (const Reinserter::Pos& q : cand) {
+        if (!(q.cost <= limit) || elapsed() >= budgetSeconds) break;
+        // (positions were found with L taken out; a position that is L's parent's old place has gone with it)
+        if (R.it[l].parent <= 0) break;
+        const int32_t sNow = R.takeOut(l);
+        if (q.item == R.it[l].parent || q.item == sNow) {
+          R.putBack(l, sNow);
+          continue;
+        }
+        R.putBack(l, q.item);
+        publish();
+        const double m = measure();
+        ++rep.probes;
+        if (m < best) {
+          gainMoves += best - m, ++nMoves;
+          best = m, ++rep.accepted, ++acceptedThisPass;
+          break;  // L has moved: its other candidates were priced for the old tree
+        }
+        R.takeOut(l);
+        R.putBack(l, sNow);
+      }
+    }
+    // (b) slot order of every inner node
+    for (size_t i = 0; i < flip.size() && elapsed() < budgetSeconds; ++i) {
+      flip[i] ^= 1;
+      publish();
+      const double m = measure();
+      ++rep.probes;
+      if (m < best) gainFlips += best - m, ++nFlips, best = m, ++rep.accepted, ++acceptedThisPass;
+      else flip[i] ^= 1;
+    }
+    if (verbose)
+      fprintf(stderr, "tune pass %d: %u accepted, cost %.6g -> %.6g, %u probes, %.2f s (so far: %u subtree moves worth %.4g, %u slot flips worth %.4g)\n",
+              pass, acceptedThisPass, rep.cost0, best, rep.probes, clock(), nMoves, gainMoves, nFlips, gainFlips);
+    if (!acceptedThisPass) break;
+  }
+  publish();
+  rep.cost1 = best, rep.seconds = clock();
+  b.maxDepth = R.it[0].height;
+  return rep;
+}
+
+// b.nodes (float boxes) -> b.nodes16 (the device records)
+void packNodes(Built& out) {
+  out.nodes16.resize(out.nodes.size());
+  for (size_t i = 0; i < out.nodes.size(); ++i) {
+    const Node& n = out.nodes[i];
+    Node16& q = out.nodes16[i];
+    for (int a = 0; a < 3; ++a) {
+      q.box0[2 * a] = toHalfDirected(n.lo0[a] * out.boxScale, false), q.box0[2 * a + 1] = toHalfDirected(n.hi0[a] * out.boxScale, true);
+      q.box1[2 * a] = toHalfDirected(n.lo1[a] * out.boxScale, false), q.box1[2 * a + 1] = toHalfDirected(n.hi1[a] * out.boxScale, true);
+      if (halfToFloat(q.box0[2 * a]) > n.lo0[a] * out.boxScale || halfToFloat(q.box0[2 * a + 1]) < n.hi0[a] * out.boxScale ||
+          halfToFloat(q.box1[2 * a]) > n.lo1[a] * out.boxScale || halfToFloat(q.box1[2 * a + 1]) < n.hi1[a] * out.boxScale)
+        throw std::runtime_error("internal error: packed box does not contain the float box");
+    }
+    // inner refs as BYTE offsets of the 32-B record (the traversal adds them to the base as they are)
+    // — and so do leaves: ~(byte offset of the first 48-B record | count - 1) (the offset is a multiple of 16)
+    for (int c = 0; c < 2; ++c) {
+      if (n.child[c] >= 0) {
+        q.child[c] = n.child[c] * 32;
+      } else {
+        const uint32_t code = ~(uint32_t)n.child[c];
+        q.child[c] = (int32_t)~((code >> 3) * 48u | (code & 7u));
+      }
+    }
+  }
+}
+
+void relayoutAndPack(Built& b) {
+  relayoutTop(b.nodes, kTopNodes);
+  packNodes(b);
+}
+
 void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threads) {
   if (leafMax == 0) leafMax = 2;  // measured on C2: 2 -> 7.35, 3 -> 7.26, 4 -> 6.63, 8 -> 4.9 Grays/s
   if (leafMax > 8) leafMax = 8;
@@ -1009,16 +1183,7 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
       out.maxDepth = R.height[0];  // (index 0 is the root before and after the relayout)
     }
   }
-  // Child 0 = the child with the SMALLER box: any-hit rays of the big-scene kernels enter it first (rt_kernels.hip
-  // Trav::round); closest-hit traversal orders by entry distance and does not care.
-  for (Node& n : out.nodes) {
-    Box b0, b1;
-    for (int a = 0; a < 3; ++a) b0.lo[a] = n.lo0[a], b0.hi[a] = n.hi0[a], b1.lo[a] = n.lo1[a], b1.hi[a] = n.hi1[a];
-    if (b1.halfArea() < b0.halfArea()) {
-      for (int a = 0; a < 3; ++a) std::swap(n.lo0[a], n.lo1[a]), std::swap(n.hi0[a], n.hi1[a]);
-      std::swap(n.child[0], n.child[1]);
-    }
-  }
+  smallerChildFirst(out.nodes);
   relayoutTop(out.nodes, kTopNodes);
   out.tris.resize(sc.n_triangles);
   for (uint32_t i = 0; i < sc.n_triangles; ++i) out.tris[i] = out.trisRef[B.prims[i].id];
@@ -1027,28 +1192,8 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   int e = 0;
   std::frexp(32768.f / std::max(maxAbs + out.pad, 1e-30f), &e);  // value = m * 2^e, m in [0.5,1)
   out.boxScale = std::ldexp(1.f, std::min(std::max(e - 1, -100), 100));
-  out.nodes16.resize(out.nodes.size());
-  for (size_t i = 0; i < out.nodes.size(); ++i) {
-    const Node& n = out.nodes[i];
-    Node16& q = out.nodes16[i];
-    for (int a = 0; a < 3; ++a) {
-      q.box0[2 * a] = toHalfDirected(n.lo0[a] * out.boxScale, false), q.box0[2 * a + 1] = toHalfDirected(n.hi0[a] * out.boxScale, true);
-      q.box1[2 * a] = toHalfDirected(n.lo1[a] * out.boxScale, false), q.box1[2 * a + 1] = toHalfDirected(n.hi1[a] * out.boxScale, true);
-      if (halfToFloat(q.box0[2 * a]) > n.lo0[a] * out.boxScale || halfToFloat(q.box0[2 * a + 1]) < n.hi0[a] * out.boxScale ||
-          halfToFloat(q.box1[2 * a]) > n.lo1[a] * out.boxScale || halfToFloat(q.box1[2 * a + 1]) < n.hi1[a] * out.boxScale)
-        throw std::runtime_error("internal error: packed box does not contain the float box");
-    }
-    // inner refs as BYTE offsets of the 32-B record (the traversal adds them to the base as they are)
-    // — and so do leaves: ~(byte offset of the first 48-B record | count - 1) (the offset is a multiple of 16)
-    for (int c = 0; c < 2; ++c) {
-      if (n.child[c] >= 0) {
-        q.child[c] = n.child[c] * 32;
-      } else {
-        const uint32_t code = ~(uint32_t)n.child[c];
-        q.child[c] = (int32_t)~((code >> 3) * 48u | (code & 7u));
-      }
-    }
-  }
+  out.depthCap = B.depthCap;
+  packNodes(out);
 }
 
 }  // namespace rtbvh

@@ -20,6 +20,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "rt_amd.h"
@@ -119,6 +120,7 @@ struct Built {
   std::vector<TriRec> tris;     // leaf order
   std::vector<TriRec> trisRef;  // reference order (brute-force kernel)
   uint32_t maxDepth = 0, leafMax = 2;
+  int depthCap = kMaxDepth - 1;  // the cap the tree was built under
   float pad = 0.f;
   float originBound = 0.f;      // ray origins with a larger |coordinate| are outside the padding analysis
   // wide form of the same tree (collapse4): empty unless requested
@@ -148,5 +150,15 @@ float halfToFloat(uint16_t h);
 // threads: builder threads (0 = one per hardware thread, at most 16); the result does not
 // depend on it.
 void build(const rt_scene_desc& scene, uint32_t leafMax, Built& out, uint32_t threads = 0);
+void packNodes(Built& b);  // b.nodes (float boxes) -> b.nodes16 (the device records)
+// Final numbering of b.nodes (most-visited top first, see bvh_build.cpp relayoutTop) + packNodes.
+void relayoutAndPack(Built& b);
+// Measured-cost tuning (bvh_build.cpp): `measure` returns the cost of the tree now in b.nodes (it packs and uploads
+// what it needs itself); moves that do not lower it are undone.  Node indices are stable during the search.
+struct TuneReport {
+  uint32_t probes = 0, accepted = 0;
+  double cost0 = 0, cost1 = 0, seconds = 0;
+};
+TuneReport tuneMeasured(Built& b, const std::function<double()>& measure, double budgetSeconds, uint32_t maxProbes, int verbose);
 
 }  // namespace rtbvh

@@ -920,6 +920,78 @@ int rt_bvh_wide_check_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t 
   return RT_OK;
 }
 
+int rt_bvh_tune(rt_ctx* c, const rt_params* probe, double budget_seconds, uint32_t max_probes, rt_tune_report* out) {
+  if (!c || !probe) return fail(RT_ERR_INVALID, "ctx/probe is null");
+  if (out) memset(out, 0, sizeof *out);
+  if (c->builder != RT_BVH_HOST || c->bvh.nodes.empty() || !c->bvh.nodes4.empty())
+    return fail(RT_ERR_STATE, "rt_bvh_tune needs a host-built binary tree");
+  if (probe->use_photons || probe->accel != RT_ACCEL_BVH) return fail(RT_ERR_INVALID, "the probe must be a BVH render without the photon map");
+  int rc = check_params(c, probe);
+  if (rc != RT_OK) return rc;
+  if (!(budget_seconds > 0)) return RT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  float4* dAcc = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAcc), (size_t)probe->width * probe->height * sizeof(float4)));
+  rt_params p = *probe;
+  p.collect_stats = 1;
+  const size_t nodeBytes = c->bvh.nodes.size() * sizeof(rtbvh::Node16);
+  std::string err;
+  auto upload = [&]() -> bool {
+    if (hipMemcpy(const_cast<uint4*>(c->S.nodes), c->bvh.nodes16.data(), nodeBytes, hipMemcpyHostToDevice) != hipSuccess) {
+      err = "node upload failed";
+      return false;
+    }
+    return true;
+  };
+  auto measure = [&]() -> double {
+    if (!err.empty()) return 1e300;
+    rtbvh::packNodes(c->bvh);
+    if (!upload()) return 1e300;
+    if (hipMemset(dAcc, 0, (size_t)p.width * p.height * sizeof(float4)) != hipSuccess) {
+      err = "probe accumulator reset failed";
+      return 1e300;
+    }
+    rt_stats st;
+    if (rt_render_device(c, &p, dAcc, nullptr, &st) != RT_OK) {
+      err = std::string("probe render failed: ") + rt_last_error();
+      return 1e300;
+    }
+    return (double)st.nodes_visited + 1.5 * (double)st.tris_tested;
+  };
+  // A second probe (another seed: other jitter, other light samples, other bounce directions) is the referee: a tuned
+  // tree that does not also beat the original on rays it was not tuned on is dropped (over-fitting shows on scenes
+  // whose probe is too small for their triangle count).
+  rtbvh::TuneReport rep;
+  bool kept = true;
+  try {
+    const std::vector<rtbvh::Node> original = c->bvh.nodes;
+    const uint32_t depth0 = c->bvh.maxDepth;
+    rt_params pv = p;
+    pv.seed = p.seed ^ 0x9e3779b9u;
+    auto referee = [&]() {
+      const rt_params keep = p;
+      p = pv;
+      const double v = measure();
+      p = keep;
+      return v;
+    };
+    const double v0 = referee();
+    rep = rtbvh::tuneMeasured(c->bvh, measure, budget_seconds, max_probes, getenv("RT_BVH_VERBOSE") != nullptr);
+    const double v1 = referee();
+    if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "tune referee probe: %.6g -> %.6g\n", v0, v1);
+    if (!(v1 < v0)) c->bvh.nodes = original, c->bvh.maxDepth = depth0, kept = false;
+    // final numbering (the LDS-resident prefix is chosen by area from the root) and the device copy
+    rtbvh::relayoutAndPack(c->bvh);
+  } catch (const std::exception& e) {
+    err = e.what();
+  }
+  if (err.empty()) upload();
+  (void)hipFree(dAcc);
+  if (!err.empty()) return fail(RT_ERR_HIP, "rt_bvh_tune: %s", err.c_str());
+  if (out) out->probes = rep.probes, out->accepted = kept ? rep.accepted : 0u, out->cost_before = rep.cost0, out->cost_after = kept ? rep.cost1 : rep.cost0, out->seconds = rep.seconds;
+  return RT_OK;
+}
+
 int rt_profile_reset(rt_ctx* c) {
   if (!c) return fail(RT_ERR_INVALID, "ctx is null");
   c->evUsed = 0;

@@ -5,7 +5,7 @@
 // value is "Missing argument" unless it is -help; unknown flags throw; a mode other
 // than 0/1 silently becomes 0), plus build-defined extensions the reference has
 // no equivalent for: -scene, -meshdir, -seed, -gpu, -gpus, -devices, -accel,
-// -progress.
+// -progress, -tune.
 #pragma once
 
 #include <cstdlib>
@@ -19,7 +19,7 @@ class CommandLine {
  public:
   CommandLine()
       : m_width(380), m_height(270), m_numRays(16), m_mode(0), m_numPhotons(0), m_k(5), m_seed(1), m_gpu(0),
-        m_accel(0), m_progress(0), m_gpus(1), m_outputFilename("output.ppm"), m_scene("cubes"), m_meshDir("../meshes") {}
+        m_accel(0), m_progress(0), m_gpus(1), m_tune(0.), m_outputFilename("output.ppm"), m_scene("cubes"), m_meshDir("../meshes") {}
   virtual ~CommandLine() {}
 
   size_t width() const { return m_width; }
@@ -34,6 +34,7 @@ class CommandLine {
   size_t gpu() const { return m_gpu; }
   size_t accel() const { return m_accel; }
   size_t progress() const { return m_progress; }
+  double tune() const { return m_tune; }
   size_t gpus() const { return m_gpus; }
   const std::string& devices() const { return m_devices; }
   const std::string& scene() const { return m_scene; }
@@ -49,6 +50,7 @@ class CommandLine {
                  "[-seed <per-pixel RNG stream key>][-gpu <HIP device>][-gpus <N: tile-shard the frame over devices gpu..gpu+N-1>]"
                  "[-devices <a,b,c: explicit device list for -gpus>][-accel <0 BVH | 1 brute force>]"
                  "[-progress <samples per update.ppm; 1 = after every pass like the reference, 0 = once>]"
+                 "[-tune <seconds: tune the BVH on probe frames of this camera before rendering (rt_bvh_tune); 0 = off>]"
               << std::endl;
   }
 
@@ -78,6 +80,7 @@ class CommandLine {
       else if (flag == "-devices") m_devices = value;
       else if (flag == "-accel") m_accel = std::atoi(value);
       else if (flag == "-progress") m_progress = std::atoi(value);
+      else if (flag == "-tune") m_tune = std::atof(value);
       else throw std::runtime_error("Unknown argument <" + flag + ">");
     }
     if (m_mode != 0 && m_mode != 1) m_mode = 0;
@@ -93,5 +96,6 @@ class CommandLine {
 
  private:
   size_t m_width, m_height, m_numRays, m_mode, m_numPhotons, m_k, m_seed, m_gpu, m_accel, m_progress, m_gpus;
+  double m_tune;
   std::string m_outputFilename, m_scene, m_meshDir, m_devices;
 };

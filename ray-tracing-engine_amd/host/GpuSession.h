@@ -76,6 +76,7 @@ struct GpuSettings {
   unsigned seed = 1;
   unsigned accel = RT_ACCEL_BVH;
   unsigned progress = 0;  // samples per launch / per update.ppm (0 = whole frame at once)
+  double tune = 0.;       // seconds of measured-cost BVH tuning before the frame (rt_bvh_tune; 0 = none)
   std::vector<int> devices;  // more than one entry: Renderer::render tile-shards the frame over them (rt_group)
   static GpuSettings& get() {
     static GpuSettings s;

@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
   GpuSettings::get().seed = static_cast<unsigned>(args.seed());
   GpuSettings::get().accel = args.accel() ? RT_ACCEL_BRUTE : RT_ACCEL_BVH;
   GpuSettings::get().progress = static_cast<unsigned>(args.progress());
+  GpuSettings::get().tune = args.tune();
   // -gpus N: devices gpu..gpu+N-1; -devices a,b,c: an explicit list (may repeat a device:
   // rehearsal of the N-rank flow on one GPU)
   if (!args.devices().empty()) {

@@ -63,6 +63,19 @@ inline void Renderer::render(Image& image) {
     }
   }
 
+  // -tune S (extension): the tree tuned on probe frames of THIS camera and integrator (rt_bvh_tune: same picture,
+  // fewer node visits; pays off on small scenes rendered with many samples)
+  if (GpuSettings::get().tune > 0. && !multi && !p.use_photons && p.accel == RT_ACCEL_BVH && p.spp > 0) {
+    rt_params probe = p;
+    const uint32_t longer = w > h ? w : h, scale = longer > 128u ? (longer + 127u) / 128u : 1u;
+    probe.width = (w + scale - 1u) / scale, probe.height = (h + scale - 1u) / scale;
+    probe.spp = 1;
+    rt_tune_report rep = {};
+    GpuSession::check(rt_bvh_tune(ctx0, &probe, GpuSettings::get().tune, 0u, &rep), "rt_bvh_tune");
+    std::cout << "BVH tuned on " << probe.width << "x" << probe.height << " probe frames: " << rep.probes << " probes, " << rep.accepted
+              << " changes kept, measured cost " << rep.cost_before << " -> " << rep.cost_after << " in " << rep.seconds << " s" << std::endl;
+  }
+
   Image result(w, h);
   if (p.spp > 0 && multi) {
     // N devices: the whole frame in one sharded launch per device (rt_group_render);

@@ -75,6 +75,11 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
+class TuneReport(C.Structure):
+    _fields_ = [("probes", C.c_uint32), ("accepted", C.c_uint32), ("cost_before", C.c_double), ("cost_after", C.c_double),
+                ("seconds", C.c_double), ("reserved", C.c_uint64 * 4)]
+
+
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_tri_records", C.c_uint32), ("max_depth", C.c_uint32),
                 ("leaf_max", C.c_uint32), ("pad", C.c_float), ("build_ms", C.c_float), ("builder", C.c_uint32),
@@ -88,7 +93,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("mesh", "<u4"), ("tri", "<u4"), ("vtx", "
 # every symbol include/rt_amd.h / include/rt_host.h declares
 AMD_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_photons", "rt_emit_photons",
                "rt_render", "rt_render_passes", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
-               "rt_bvh_export", "rt_bvh_build_host", "rt_bvh_wide_check_host", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
+               "rt_bvh_export", "rt_bvh_build_host", "rt_bvh_wide_check_host", "rt_bvh_tune", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
                "rt_trace_stream_device", "rt_build_photon_map", "rt_get_photons", "rt_test_kd_order", "rt_owned_granules", "rt_pack_owned_device", "rt_unpack_owned_device", "rt_group_create", "rt_group_destroy",
                "rt_group_size", "rt_group_uses_rccl", "rt_group_ctx", "rt_group_set_photons", "rt_group_render"]
 HOST_SYMBOLS = ["rt_host_scene_build", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error",
@@ -136,6 +141,7 @@ def amd():
         L.rt_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_bvh_info_get.argtypes = [C.c_void_p, C.POINTER(BvhInfo)]
         L.rt_bvh_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_bvh_tune.argtypes = [C.c_void_p, C.POINTER(Params), C.c_double, C.c_uint32, C.POINTER(TuneReport)]
         L.rt_bvh_build_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.POINTER(BvhInfo),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.rt_bvh_wide_check_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -289,6 +295,12 @@ class Context:
         bi = BvhInfo()
         _check(amd().rt_bvh_info_get(self._h, C.byref(bi)))
         return bi
+
+    def tune(self, probe_params, budget_seconds, max_probes=0):
+        """rt_bvh_tune: measured-cost tuning of the host-built tree against the rays of `probe_params`."""
+        rep = TuneReport()
+        _check(amd().rt_bvh_tune(self._h, C.byref(probe_params), float(budget_seconds), int(max_probes), C.byref(rep)))
+        return rep
 
     def bvh_export(self):
         bi = self.bvh_info()

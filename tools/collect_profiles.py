@@ -31,7 +31,7 @@ for name, to in (("c2_kernel_stats.csv", R + "_c2_kernel_stats.csv"), ("c2_pmc_s
                  ("c5_pmc_spp32.txt", R + "_c5_pmc_spp32.txt"), ("phase_C2.json", R + "_phase_C2.json"),
                  ("phase_C4.json", R + "_phase_C4.json"), ("phase_C5.json", R + "_phase_C5.json"), ("builders.txt", R + "_builders.txt"),
                  ("stream_vs_megakernel.json", R + "_stream_vs_megakernel.json"),
-                 ("bench_C2_under_rocprof.json", R + "_bench_C2_under_rocprof.json"),
+                 ("bench_C2_under_rocprof.json", R + "_bench_C2_under_rocprof.json"), ("bench_C2_tuned.json", R + "_bench_C2_tuned.json"),
                  ("c2_pmc_ta.txt", R + "_c2_pmc_ta.txt"), ("c5_pmc_ta.txt", R + "_c5_pmc_ta.txt"),
                  ("c2_pmc_issue.txt", R + "_c2_pmc_issue.txt"), ("c5x8_pmc_spp8.txt", R + "_c5x8_pmc_spp8.txt"),
                  ("c3_pmc.txt", R + "_c3_pmc.txt"), ("gather_microbench.json", R + "_gather_microbench.json")):

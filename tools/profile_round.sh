@@ -8,6 +8,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/round; mkdir -p $out
 python3 bench.py --steps 20 --warmup 5 --cpu-baseline-full > $out/bench_C2.log 2>&1; grep '^{' $out/bench_C2.log > $out/bench_C2.json
+python3 bench.py --tune-probes 1500 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_C2_tuned.log 2>&1; grep '^{' $out/bench_C2_tuned.log > $out/bench_C2_tuned.json
 echo "C2 done"
 for w in C1 C3 C4 C5 C5x8; do
   python3 bench.py --workload $w --no-cpu-baseline --steps 5 --warmup 2 > $out/bench_$w.log 2>&1; grep '^{' $out/bench_$w.log > $out/bench_$w.json
