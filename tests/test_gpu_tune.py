@@ -13,7 +13,8 @@ import orc
 import pyrt
 from raybatch import ray_batch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(bool(os.environ.get("RT_BVH_GPU")), reason="RT_BVH_GPU forces the device builder: no host-side tree to tune")]
 
 
 def bits(a):
