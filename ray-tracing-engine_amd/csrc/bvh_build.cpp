@@ -1185,6 +1185,21 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   }
   smallerChildFirst(out.nodes);
   relayoutTop(out.nodes, kTopNodes);
+  if (const char* e = getenv("RT_BVH_TUNE_AREA")) {
+    // The tuner (tuneMeasured) driven by a cost the host can compute — the summed surface area of the child boxes —
+    // instead of a probe frame's counters: no use for rendering (that is what the reinsertion passes do, better), but
+    // it runs the tuner's whole machinery (proposals, undo, slot flips, depth bound) without a GPU: tests/test_bvh_wide_host.py.
+    const uint32_t probes = (uint32_t)std::max(0, atoi(e));
+    if (probes) {
+      auto area = [&out]() {
+        double a = 0;
+        for (const Node& n : out.nodes) a += Rotator::childBox(n, 0).halfArea() + Rotator::childBox(n, 1).halfArea();
+        return a;
+      };
+      tuneMeasured(out, area, 1e9, probes, getenv("RT_BVH_VERBOSE") != nullptr);
+      relayoutTop(out.nodes, kTopNodes);
+    }
+  }
   out.tris.resize(sc.n_triangles);
   for (uint32_t i = 0; i < sc.n_triangles; ++i) out.tris[i] = out.trisRef[B.prims[i].id];
 

@@ -54,3 +54,20 @@ def test_reinsertion_passes_keep_the_tree_valid_and_lower_its_surface_area(kind,
     opt = pyrt.bvh_wide_check_host(s, 0, 30)
     assert opt["binary_nodes"] == base["binary_nodes"] and opt["binary_depth"] <= base["binary_depth"] + 3
     assert opt["visits2"] < 0.99 * base["visits2"]
+
+
+@pytest.mark.parametrize("kind", ["cubes", "lowres"])
+def test_tuner_machinery_on_a_host_computable_cost(kind, monkeypatch):
+    """bvh_build.cpp tuneMeasured (what rt_bvh_tune drives with a probe frame's counters) run on a cost the host can
+    compute, the summed surface area of the child boxes (RT_BVH_TUNE_AREA=probes): proposals, undo of rejected moves,
+    slot flips and the depth bound all run without a GPU, and the structure check must still pass — every triangle once,
+    boxes containing their padded geometry, no leaf deeper than before."""
+    s = pyrt.Scene(kind, 32, 32)
+    monkeypatch.setenv("RT_BVH_ROT", "0")
+    base = pyrt.bvh_wide_check_host(s, 0, 30)
+    monkeypatch.setenv("RT_BVH_TUNE_AREA", "400")
+    tuned = pyrt.bvh_wide_check_host(s, 0, 30)
+    assert tuned["binary_nodes"] == base["binary_nodes"] and tuned["binary_depth"] <= base["binary_depth"]
+    assert tuned["visits2"] <= base["visits2"]
+    if kind == "lowres":
+        assert tuned["visits2"] < 0.995 * base["visits2"]
