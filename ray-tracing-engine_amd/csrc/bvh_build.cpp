@@ -1209,6 +1209,27 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   out.boxScale = std::ldexp(1.f, std::min(std::max(e - 1, -100), 100));
   out.depthCap = B.depthCap;
   packNodes(out);
+  if (getenv("RT_BVH_VERBOSE")) {
+    // what the 16-bit plane encodings cost in box surface (the traversal visits boxes roughly in proportion to it):
+    // binary16 of coordinate x boxScale (what the kernels read) against a 16-bit fixed-point grid over the scene
+    double aF = 0, aH = 0, aX = 0;
+    int ex = 0;
+    std::frexp((maxAbs + out.pad) * 2.f / 65534.f, &ex);
+    const float step = std::ldexp(1.f, ex);  // power of two >= range / 65534
+    for (size_t i = 0; i < out.nodes.size(); ++i)
+      for (int c = 0; c < 2; ++c) {
+        const Box b = Rotator::childBox(out.nodes[i], c);
+        const uint16_t* q = c ? out.nodes16[i].box1 : out.nodes16[i].box0;
+        Box h, x;
+        for (int a = 0; a < 3; ++a) {
+          h.lo[a] = halfToFloat(q[2 * a]) / out.boxScale, h.hi[a] = halfToFloat(q[2 * a + 1]) / out.boxScale;
+          x.lo[a] = std::floor(b.lo[a] / step) * step, x.hi[a] = std::ceil(b.hi[a] / step) * step;
+        }
+        aF += b.halfArea(), aH += h.halfArea(), aX += x.halfArea();
+      }
+    fprintf(stderr, "box surface: float %.6g, binary16 planes %.6g (+%.2f %%), 16-bit fixed point (step %g) %.6g (+%.2f %%)\n", aF, aH,
+            100 * (aH / aF - 1), (double)step, aX, 100 * (aX / aF - 1));
+  }
 }
 
 }  // namespace rtbvh
