@@ -289,7 +289,11 @@ class Context:
             amd().rt_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter exit module globals / ctypes may already be torn down
+            self.close()
+        except Exception:
+            pass
 
     def bvh_info(self):
         bi = BvhInfo()
@@ -435,7 +439,11 @@ class Group:
             amd().rt_group_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def size(self):
