@@ -496,6 +496,25 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   // beyond that every step waits on the vector L1, and leaving the descent with up to 24 lanes still
   // in it plus refilling at 32 hands out work sooner (C5 328.5 -> 317.4 ms, C5x8 55.0 -> 52.4 ms;
   // profiles/r03_pool_thresholds.txt).
+  // 1 / det of the triangle test (rt_device.h tri_test): the three-instruction reciprocal is bit-identical to the
+  // division for |det| < 2^100 (exhaustive check, tools/microbench/recip_exact.hip), and |det| = |e1 . (d x e2)| <=
+  // |e1| |e2| |d|: edges are at most 2 sqrt(3) maxAbs long, and the rays the RENDER kernels make are unit vectors
+  // (camera, bounce, photon emission) or run from a surface point to a light sample.  Outside that bound — or for a
+  // non-finite light — the kernels divide.  (User rays: rt_trace / rt_trace_stream_device always divide.)
+  {
+    double maxAbs = 0, maxLight = 0;
+    for (size_t i = 0; i < 3 * (size_t)sc->n_vertices; ++i) maxAbs = std::max(maxAbs, (double)std::fabs(sc->vertex_pos[i]));
+    for (uint32_t l = 0; l < sc->n_lights; ++l) {
+      const rt_light& L = sc->lights[l];
+      double pos = 0, ver = 0, hor = 0;
+      for (int a = 0; a < 3; ++a) pos += (double)L.position[a] * L.position[a], ver += (double)L.vertical[a] * L.vertical[a], hor += (double)L.horizontal[a] * L.horizontal[a];
+      maxLight = std::max(maxLight, std::sqrt(pos) + std::fabs((double)L.side) * (std::sqrt(ver) + std::sqrt(hor)));
+    }
+    const double edge = 2.0 * 1.7320508 * maxAbs, dir = 1.7320508 * maxAbs + maxLight + 2.0;
+    const double detBound = 1.01 * edge * edge * dir;
+    S.slowRecip = (std::isfinite(detBound) && detBound < 1.2676506e30) ? 0u : 1u;
+    if (getenv("RT_SLOW_RECIP")) S.slowRecip = 1u;  // (A/B and the parity tests of the division path)
+  }
   const bool bigTree = S.n_nodes > 65536;
   S.leafT = getenv("RT_LEAFT") ? atoi(getenv("RT_LEAFT")) : bigTree ? 32 : 12;
   S.leafMul = getenv("RT_LEAFMUL") ? atoi(getenv("RT_LEAFMUL")) : bigTree ? 32 : 22;
@@ -753,7 +772,9 @@ int rt_trace(rt_ctx* c, const rt_ray* rays, uint32_t n, uint32_t accel, uint32_t
     (void)hipFree(dR);
     return fail(RT_ERR_HIP, "hit buffer allocation failed");
   }
-  hipError_t he = rtk::launch_trace(accel == RT_ACCEL_BRUTE, kind == RT_TRACE_ANY, c->S, dR, n, dH, c->dCounters, nullptr);
+  rtk::DevScene Su = c->S;
+  Su.slowRecip = 1u;  // the caller's rays: any length
+  hipError_t he = rtk::launch_trace(accel == RT_ACCEL_BRUTE, kind == RT_TRACE_ANY, Su, dR, n, dH, c->dCounters, nullptr);
   if (he == hipSuccess) he = hipMemcpy(hits, dH, n * sizeof(rt_hit), hipMemcpyDeviceToHost);
   (void)hipFree(dR), (void)hipFree(dH);
   if (he != hipSuccess) return fail(RT_ERR_HIP, "trace failed: %s", hipGetErrorString(he));
@@ -1014,9 +1035,9 @@ int rt_profile_collect(rt_ctx* c, double* total_ms, uint32_t* launches) {
 }
 
 int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint32_t n) {
-  static const uint32_t inBytes[] = {8, 4, 4, 16, 60, 68, 56, 96, 112, 88, 8};
-  static const uint32_t outBytes[] = {8, 4, 4, 4, 16, 12, 24, 12, 48, 16, 16};
-  if (which > RT_UNIT_POW) return fail(RT_ERR_INVALID, "unknown unit %u", which);
+  static const uint32_t inBytes[] = {8, 4, 4, 16, 60, 68, 56, 96, 112, 88, 8, 4};
+  static const uint32_t outBytes[] = {8, 4, 4, 4, 16, 12, 24, 12, 48, 16, 16, 8};
+  if (which > RT_UNIT_RECIP) return fail(RT_ERR_INVALID, "unknown unit %u", which);
   if (n && (!in || !out)) return fail(RT_ERR_INVALID, "null argument");
   if (n == 0) return RT_OK;
   int rc = select_device(device);
@@ -1039,7 +1060,9 @@ int rt_trace_stream_device(rt_ctx* c, const void* d_ray_o, const void* d_ray_d, 
   if (!c || (n && (!d_ray_o || !d_ray_d || !d_res))) return fail(RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->device));
   const uint32_t levels = (c->bvh.maxDepth > 1 ? c->bvh.maxDepth : 1) + 1u;
-  hipError_t he = rtk::launch_trace_stream(c->S, static_cast<const float4*>(d_ray_o), static_cast<const float4*>(d_ray_d), n,
+  rtk::DevScene Su = c->S;
+  Su.slowRecip = 1u;  // the caller's rays: any length
+  hipError_t he = rtk::launch_trace_stream(Su, static_cast<const float4*>(d_ray_o), static_cast<const float4*>(d_ray_d), n,
                                            static_cast<uint2*>(d_res), c->dTileCounter, levels, c->numCUs,
                                            static_cast<hipStream_t>(stream));
   if (he != hipSuccess) return fail(RT_ERR_HIP, "stream trace launch failed: %s", hipGetErrorString(he));

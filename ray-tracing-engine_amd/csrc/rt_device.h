@@ -39,6 +39,17 @@ RT_DEV f3 cross3(f3 a, f3 b) {
 // NB: __fsqrt_rn() lowers to a bare v_sqrt_f32 (1 ulp) on gfx950; sqrtf / __builtin_sqrtf
 // get the correctly rounded expansion (v_sqrt_f32 + residual fix-up).
 RT_DEV float len3(f3 a) { return __builtin_sqrtf(dot3(a, a)); }
+// 1.0f / x in three instructions (v_rcp_f32 + one Newton step) instead of the eleven of the correctly rounded
+// expansion — and the SAME BITS for every x with 2^-100 <= |x| < 2^101: checked exhaustively on gfx950 over all 2^32
+// inputs (tools/microbench/recip_exact.hip, profiles/r03_recip_exact.json: 0 mismatches in that range; outside it —
+// results in or near the denormal range, zero, infinity, NaN — the two differ, so every caller guards its range and
+// takes the division there).
+RT_DEV float recip_fast(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+constexpr float kRecipLo = 7.888609e-31f;  // 2^-100
+constexpr float kRecipHi = 1.2676506e30f;  // 2^100
 // Vec3.h:170-178 — null vectors stay null, otherwise multiply by 1/len
 RT_DEV f3 unit3(f3 a) {
   float l = len3(a);
@@ -191,14 +202,8 @@ RT_DEV f3 bsdf_eval(const rt_material& m, f3 normal, f3 wi_in, f3 wo_in) {
 // ------------------------------------------------------------------ triangle test
 // Ray.cpp:9-24 on a flattened record (p0, e1 = p1-p0, e2 = p2-p0 precomputed with
 // the same float subtraction the reference performs per test).
-RT_DEV bool tri_test(f3 o, f3 d, f3 p0, f3 e1, f3 e2, float& u, float& v, float& t) {
-  // Branch-free form: the reference returns early when |det| < EPSILON or u is out of
-  // range; here everything is evaluated (a zero det just yields inf/NaN values that
-  // the combined predicate discards) so that a wave never splits inside the test.
-  // The RESULT (bool and, when true, u v t) is the reference's bit for bit.
-  f3 pvec = cross3(d, e2);
-  float det = dot3(e1, pvec);
-  float inv = 1.0f / det;
+// (the part of the test behind the reciprocal of the determinant)
+RT_DEV bool tri_finish(f3 o, f3 d, f3 p0, f3 e1, f3 e2, f3 pvec, float det, float inv, float& u, float& v, float& t) {
   f3 tvec = o - p0;
   u = dot3(tvec, pvec) * inv;
   f3 qvec = cross3(tvec, e1);
@@ -208,7 +213,21 @@ RT_DEV bool tri_test(f3 o, f3 d, f3 p0, f3 e1, f3 e2, float& u, float& v, float&
   const bool uOk = !(u < 0.f || u > 1.f);
   return detOk && uOk && v >= 0.f && u + v <= 1.f;
 }
-
+// `divide` (a compile-time constant at every call site) = this kernel instance's rays are not known to keep |det| below
+// 2^100 (rt_kernels.hip LT_FASTDET): 1 / det by the division.
+RT_DEV bool tri_test(f3 o, f3 d, f3 p0, f3 e1, f3 e2, float& u, float& v, float& t, bool divide) {
+  // Branch-free form: the reference returns early when |det| < EPSILON or u is out of
+  // range; here everything is evaluated (a zero det just yields inf/NaN values that
+  // the combined predicate discards) so that a wave never splits inside the test.
+  // The RESULT (bool and, when true, u v t) is the reference's bit for bit.
+  f3 pvec = cross3(d, e2);
+  float det = dot3(e1, pvec);
+  // 1 / det: three instructions where the host has bounded |det| for every ray this launch can produce (rt_api.cpp
+  // create_ctx: longest edge^2 x longest ray direction < 2^100; a determinant below recip_fast's range is below
+  // EPSILON too and rejected whatever inv holds), the division otherwise.  Same bits either way.
+  const float inv = divide ? 1.0f / det : recip_fast(det);
+  return tri_finish(o, d, p0, e1, e2, pvec, det, inv, u, v, t);
+}
 // Same test with the reference's early exits (leaves u, v, t untouched exactly where
 // Ray.cpp:9-24 does) — the unit-test hook compares those side effects too.
 RT_DEV bool tri_test_ref_order(f3 o, f3 d, f3 p0, f3 e1, f3 e2, float& u, float& v, float& t) {

@@ -52,6 +52,7 @@ struct DevScene {
   float originBound;       // k_trace: rays starting farther out run the exhaustive loop (rtbvh::Built)
   uint32_t leafT;          // Trav::round leaves its descent when fewer lanes than this still descend ...
   uint32_t leafMul;        // ... and fewer than leafMul/64 of the wave's live lanes
+  uint32_t slowRecip;      // 1: 1 / det by division (rays of unknown length); 0: rtd::recip_fast — |det| < 2^100 is guaranteed
   uint32_t refillT;        // vertex_pool hands out rays once this many workers are free
   uint32_t stealT;         // ... and splits the stacks of the last long rays once this many are free
   rt_camera cam;

@@ -193,6 +193,9 @@ constexpr int LT_WIDE = 64;
 // CU-level ray sharing (vertex_pool_cus): a wave whose own pool has no rays left to hand out takes
 // fresh rays from the pools of the other waves of its workgroup instead of idling through its tail.
 constexpr int LT_CUS = 128;
+// 1 / det of the triangle test by rtd::recip_fast (3 instructions, the division's bits for |det| < 2^100) instead of the
+// division: only the instances the launcher picks when the host has bounded |det| for the launch's rays (DevScene::slowRecip == 0).
+constexpr int LT_FASTDET = 256;
 constexpr uint32_t kPrioMaxNodes = 65536;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
@@ -203,6 +206,7 @@ struct Trav {
   static constexpr bool SS = (LTX & LT_SS) != 0;
   static constexpr bool PRIO = (LTX & LT_NOPRIO) == 0;
   static constexpr bool WIDE = (LTX & LT_WIDE) != 0;
+  static constexpr bool DIVIDE = (LTX & LT_FASTDET) == 0;
   // any-hit rays enter child 0 (the smaller box) first: the big-scene instances and the whole-tree-in-LDS ones (measured:
   // C5 -2.5 %, C5x8 -1.9 %, C2 -0.7 %, C1 -3 %; the partial-top instance of C4 loses 0.7 % to the extra scalar op and keeps
   // the distance order)
@@ -462,8 +466,8 @@ struct Trav {
                         const float4& q2, bool two, LaneStats& st) {
     if (STATS) st.tris += two ? 2u : 1u;
     float ua, va, ta, ub, vb, tb;
-    const bool ha = tri_test(o, d, mk(p0.x, p0.y, p0.z), mk(p0.w, p1.x, p1.y), mk(p1.z, p1.w, p2.x), ua, va, ta) && ta > 0.f;
-    const bool hb = tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ub, vb, tb) && tb > 0.f && two;
+    const bool ha = tri_test(o, d, mk(p0.x, p0.y, p0.z), mk(p0.w, p1.x, p1.y), mk(p1.z, p1.w, p2.x), ua, va, ta, DIVIDE) && ta > 0.f;
+    const bool hb = tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ub, vb, tb, DIVIDE) && tb > 0.f && two;
     const bool isAny = MODE == TRAV_ANY || (MODE == TRAV_MIXED && anyHit);
     const uint32_t ida = __float_as_uint(p2.y), idb = __float_as_uint(q2.y);
     const bool ba = !isAny && ha && (ta < best || (ta == best && ida < bestId));
@@ -488,7 +492,7 @@ struct Trav {
   RT_DEV bool test_record(const float4& q0, const float4& q1, const float4& q2, LaneStats& st) {
     if (STATS) st.tris++;
     float u, v, t;
-    if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t) && t > 0.f) {
+    if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t, DIVIDE) && t > 0.f) {
       if (MODE == TRAV_ANY || (MODE == TRAV_MIXED && anyHit)) {
         found = true;
         return true;
@@ -548,7 +552,7 @@ RT_DEV bool brute(const DevScene& S, f3 o, f3 d, HitRec& hit, LaneStats& st) {
     const float4* r = S.trisRef + 3 * (size_t)i;  // wave-uniform address -> scalar loads
     const float4 q0 = r[0], q1 = r[1], q2 = r[2];
     float u, v, t;
-    if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t)) {
+    if (tri_test(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), u, v, t, true)) {
       if (t > 0.f && t < best) {
         if (ANY) return true;
         best = t, found = true;
@@ -767,7 +771,7 @@ RT_DEV void vertex_setup_ray(const DevScene& S, uint32_t id, f3 o, f3 d, f3& hit
   const uint4 tv = S.triShade[id];
   const f3 p0 = ld(S.vpos + 3 * (size_t)tv.x), p1 = ld(S.vpos + 3 * (size_t)tv.y), p2 = ld(S.vpos + 3 * (size_t)tv.z);
   float u, v, t;
-  tri_test(o, d, p0, p1 - p0, p2 - p0, u, v, t);
+  tri_test(o, d, p0, p1 - p0, p2 - p0, u, v, t, true);  // (once per vertex: the division; the same bits as the walker's)
   const float w = 1.f - u - v;
   hitNormal = unit3(interp3(S.vnrm, tv, w, u, v));
   point = w * p0 + u * p1 + v * p2;
@@ -1925,6 +1929,11 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
       ((double*)out)[2 * (size_t)i] = rt_pow2(x), ((double*)out)[2 * (size_t)i + 1] = rt_pow5(x);
       break;
     }
+    case RT_UNIT_RECIP: {  // in: float x; out: rtd::recip_fast(x), 1.0f / x
+      const float x = ((const float*)in)[i];
+      ((float*)out)[2 * (size_t)i] = rtd::recip_fast(x), ((float*)out)[2 * (size_t)i + 1] = 1.0f / x;
+      break;
+    }
     default:
       break;
   }
@@ -2049,6 +2058,12 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
     hipLaunchKernelGGL((k_render_persist<ST, LTV>), dim3(wgs), dim3(64u * P.waves), P.ldsBytes + 4u * rtbvh::kCtlWords, \
                        stream, S2, A2, accum, counters);                                                                \
   } while (0)
+      // the timed (uncounted) default instances: with the three-instruction 1 / det where the host has bounded |det|
+#define RT_LAUNCH_FAST(LTV)                                       \
+  do {                                                            \
+    if (S.slowRecip) RT_LAUNCH_PERSIST(false, LTV);               \
+    else RT_LAUNCH_PERSIST(false, (LTV) | LT_FASTDET);            \
+  } while (0)
       // CU-level ray sharing (vertex_pool_cus): OPT-IN, RT_CUSHARE=1.  Built, bit-exact and measured:
       // C2 66.2 vs 50.8 ms, lanes per node step 29.4 vs 36.4 — sharing balances the 16 pools of a CU, so they drain
       // together and the tail becomes CU-wide; what bounds a pool is the dependency chain of its samples (one
@@ -2069,14 +2084,14 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
         }
       } else if (P.compact == 2) {
         if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT2);
-        else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT2);
+        else RT_LAUNCH_FAST(LT_NONE | LT_NOPRIO | LT_COMPACT2);
       } else if (P.compact) {
         if (cus) {
           if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT | LT_CUS);
           else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT | LT_CUS);
         } else {
           if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT);
-          else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT);
+          else RT_LAUNCH_FAST(LT_NONE | LT_NOPRIO | LT_COMPACT);
         }
       } else if (P.ssRows) {
         if (stats) {
@@ -2104,11 +2119,12 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
         else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO);
         else RT_LAUNCH_PERSIST(true, LT_NONE);
       } else {
-        if (lt == LT_ALL) RT_LAUNCH_PERSIST(false, LT_ALL);
-        else if (lt == LT_TOP) RT_LAUNCH_PERSIST(false, LT_TOP);
-        else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO);
-        else RT_LAUNCH_PERSIST(false, LT_NONE);
+        if (lt == LT_ALL) RT_LAUNCH_FAST(LT_ALL);
+        else if (lt == LT_TOP) RT_LAUNCH_FAST(LT_TOP);
+        else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_FAST(LT_NONE | LT_NOPRIO);
+        else RT_LAUNCH_FAST(LT_NONE);
       }
+#undef RT_LAUNCH_FAST
 #undef RT_LAUNCH_PERSIST
       return hipGetLastError();
     }
