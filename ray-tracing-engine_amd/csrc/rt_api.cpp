@@ -496,23 +496,40 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   // beyond that every step waits on the vector L1, and leaving the descent with up to 24 lanes still
   // in it plus refilling at 32 hands out work sooner (C5 328.5 -> 317.4 ms, C5x8 55.0 -> 52.4 ms;
   // profiles/r03_pool_thresholds.txt).
-  // 1 / det of the triangle test (rt_device.h tri_test): the three-instruction reciprocal is bit-identical to the
-  // division for |det| < 2^100 (exhaustive check, tools/microbench/recip_exact.hip), and |det| = |e1 . (d x e2)| <=
-  // |e1| |e2| |d|: edges are at most 2 sqrt(3) maxAbs long, and the rays the RENDER kernels make are unit vectors
-  // (camera, bounce, photon emission) or run from a surface point to a light sample.  Outside that bound — or for a
-  // non-finite light — the kernels divide.  (User rays: rt_trace / rt_trace_stream_device always divide.)
+  // The short reciprocal (rt_device.h recip_fast: v_rcp_f32 + one Newton step, the division's bits for 2^-100 <= |x| < 2^101
+  // — exhaustive check, tools/microbench/recip_exact.hip) replaces the division in the default render instances
+  // (rt_kernels.hip LT_FASTDET) in two places, and the host vouches for the range here:
+  //  * 1 / det of the triangle test: |det| = |e1 . (d x e2)| <= |e1| |e2| |d|; edges are at most 2 sqrt(3) maxAbs long, and
+  //    the rays the RENDER kernels make are unit vectors (camera, bounce) or run from a surface point to a light sample;
+  //  * 1 / length in normalisations: a length is sqrt(float) — 0, or >= 2^-74.5 — and finite as long as no dot product
+  //    overflows: every vector the kernels normalise is a small sum of scene inputs, so |input| <= 1e17 keeps the
+  //    squares below 3.4e38.
+  // Outside these bounds — or with any non-finite input — the kernels divide.  (User rays, rt_trace /
+  // rt_trace_stream_device, always divide.)
   {
-    double maxAbs = 0, maxLight = 0;
+    double maxAbs = 0, maxLight = 0, maxAny = 0;
+    bool finite = true;
+    auto eat = [&](const float* p, size_t n) {
+      for (size_t i = 0; i < n; ++i) {
+        finite = finite && std::isfinite(p[i]);
+        maxAny = std::max(maxAny, (double)std::fabs(p[i]));
+      }
+    };
     for (size_t i = 0; i < 3 * (size_t)sc->n_vertices; ++i) maxAbs = std::max(maxAbs, (double)std::fabs(sc->vertex_pos[i]));
+    eat(sc->vertex_pos, 3 * (size_t)sc->n_vertices);
+    eat(sc->vertex_nrm, 3 * (size_t)sc->n_vertices);
+    eat(sc->camera.position, 12);
     for (uint32_t l = 0; l < sc->n_lights; ++l) {
       const rt_light& L = sc->lights[l];
+      eat(L.position, 15);
+      eat(&L.intensity, 6);
       double pos = 0, ver = 0, hor = 0;
       for (int a = 0; a < 3; ++a) pos += (double)L.position[a] * L.position[a], ver += (double)L.vertical[a] * L.vertical[a], hor += (double)L.horizontal[a] * L.horizontal[a];
       maxLight = std::max(maxLight, std::sqrt(pos) + std::fabs((double)L.side) * (std::sqrt(ver) + std::sqrt(hor)));
     }
     const double edge = 2.0 * 1.7320508 * maxAbs, dir = 1.7320508 * maxAbs + maxLight + 2.0;
     const double detBound = 1.01 * edge * edge * dir;
-    S.slowRecip = (std::isfinite(detBound) && detBound < 1.2676506e30) ? 0u : 1u;
+    S.slowRecip = (finite && maxAny <= 1e17 && maxLight <= 1e17 && std::isfinite(detBound) && detBound < 1.2676506e30) ? 0u : 1u;
     if (getenv("RT_SLOW_RECIP")) S.slowRecip = 1u;  // (A/B and the parity tests of the division path)
   }
   const bool bigTree = S.n_nodes > 65536;

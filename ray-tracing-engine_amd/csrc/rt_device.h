@@ -50,11 +50,16 @@ RT_DEV float recip_fast(float x) {
 }
 constexpr float kRecipLo = 7.888609e-31f;  // 2^-100
 constexpr float kRecipHi = 1.2676506e30f;  // 2^100
-// Vec3.h:170-178 — null vectors stay null, otherwise multiply by 1/len
+// Vec3.h:170-178 — null vectors stay null, otherwise multiply by 1/len.
+// FAST (a compile-time choice of the kernel instance, rt_kernels.hip LT_FASTDET): 1 / len by recip_fast.  l = sqrt(float)
+// is 0 (handled), or >= 2^-74.5 (the root of the smallest denormal), and at most 2^64 unless the dot product overflowed
+// or was NaN — which the host has excluded for the instances that say FAST (rt_api.cpp create_ctx bounds every input of
+// the scene): inside recip_fast's range, so the same bits as the division.
+template <bool FAST = false>
 RT_DEV f3 unit3(f3 a) {
   float l = len3(a);
   if (l == 0.f) return a;
-  float inv = 1.0f / l;
+  const float inv = FAST ? recip_fast(l) : 1.0f / l;
   return mk(a.x * inv, a.y * inv, a.z * inv);
 }
 RT_DEV float dist3(f3 a, f3 b) { return len3(a - b); }
@@ -104,29 +109,31 @@ RT_DEV void two_orthogonals(f3 n, f3& u, f3& v) {
 }
 
 // RayTracer.h:95-107 with maxRayAngle = float(pi/2) (its only call value)
+template <bool FAST = false>
 RT_DEV f3 hemisphere_sample(Rng& g, f3 normal) {
   const float maxRayAngle = 1.57079637f;
   const double PI = 3.14159265358979323846;
   const double hi = (double)(2 * maxRayAngle) / PI;
-  normal = unit3(normal);
+  normal = unit3<FAST>(normal);
   f3 v1, v2;
   two_orthogonals(normal, v1, v2);
-  v1 = unit3(v1);
-  v2 = unit3(v2);
+  v1 = unit3<FAST>(v1);
+  v2 = unit3<FAST>(v2);
   float theta = (float)rt_asin(g.uniformD(0.0, hi));
   float phi = (float)(2 * PI * g.uniformD(0.0, hi));
   float sp, cp, st, ct;
   rt_sincosf(phi, &sp, &cp);
   rt_sincosf(theta, &st, &ct);
-  f3 dir = unit3(v1 * cp + v2 * sp);
-  return unit3(normal * ct + dir * st);
+  f3 dir = unit3<FAST>(v1 * cp + v2 * sp);
+  return unit3<FAST>(normal * ct + dir * st);
 }
 
 // ------------------------------------------------------------------ camera / lights
 // Camera.h:27-30
+template <bool FAST = false>
 RT_DEV void camera_ray(const rt_camera& c, float u, float v, f3& o, f3& d) {
   o = ld(c.position);
-  d = unit3(ld(c.lower_left) + u * ld(c.horizontal) + v * ld(c.vertical) - o);
+  d = unit3<FAST>(ld(c.lower_left) + u * ld(c.horizontal) + v * ld(c.vertical) - o);
 }
 
 // LightSource.h:46-49; first draw scales the horizontal axis (g++ evaluation order)
@@ -167,9 +174,10 @@ struct BsdfBase {
   f3 n, wo, F0, oneMinusF0, kdDiffuse;
   float alpha, a2, gwo, nwo, oneMinusKd;
 };
+template <bool FAST = false>
 RT_DEV BsdfBase bsdf_base(const rt_material& m, f3 normal, f3 wo_in) {
   BsdfBase B;
-  B.n = unit3(normal), B.wo = unit3(wo_in);
+  B.n = unit3<FAST>(normal), B.wo = unit3<FAST>(wo_in);
   B.alpha = m.alpha, B.a2 = m.alpha * m.alpha;
   B.F0 = ld(m.f0), B.oneMinusF0 = mk(1.f, 1.f, 1.f) - B.F0;
   B.gwo = g_schlick(m.alpha, B.wo, B.n);
@@ -178,10 +186,11 @@ RT_DEV BsdfBase bsdf_base(const rt_material& m, f3 normal, f3 wo_in) {
   B.kdDiffuse = m.kd * diffuse, B.oneMinusKd = 1 - m.kd;
   return B;
 }
+template <bool FAST = false>
 RT_DEV f3 bsdf_apply(const BsdfBase& B, f3 wi_in) {
   const double PI = 3.14159265358979323846;
-  f3 wi = unit3(wi_in);
-  f3 wh = unit3(wi + B.wo);
+  f3 wi = unit3<FAST>(wi_in);
+  f3 wh = unit3<FAST>(wi + B.wo);
   float D = (float)((double)B.a2 / (PI * rt_pow2(1 + (double)(B.a2 - 1) * rt_pow2((double)dot3(B.n, wh)))));
   double c = (double)dot3(wi, wh);
   float f5 = (float)rt_pow5(1 - (c > 0.0 ? c : 0.0));  // fmax(0, c); NaN -> 0 like fmax

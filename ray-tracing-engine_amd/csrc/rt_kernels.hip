@@ -755,10 +755,11 @@ RT_DEV uint32_t lanes_below(uint64_t m) {  // number of set bits of m below this
 }
 
 // Renderer.cpp:42-43: interpolated shading normal and hit point
+template <bool FAST = false>
 RT_DEV void vertex_setup(const DevScene& S, const HitRec& h, f3& hitNormal, f3& point) {
   const float w = 1.f - h.u - h.v;
   const uint4 tv = S.triShade[h.id];
-  hitNormal = unit3(interp3(S.vnrm, tv, w, h.u, h.v));
+  hitNormal = unit3<FAST>(interp3(S.vnrm, tv, w, h.u, h.v));
   point = interp3(S.vpos, tv, w, h.u, h.v);
 }
 
@@ -767,13 +768,14 @@ RT_DEV void vertex_setup(const DevScene& S, const HitRec& h, f3& hitNormal, f3& 
 // walker's record holds — p0 and the float edge differences bvh_build.cpp stores —
 // so they are the bits the walker had; the vertex loads are the ones the
 // interpolation needs anyway.
+template <bool FAST = false>
 RT_DEV void vertex_setup_ray(const DevScene& S, uint32_t id, f3 o, f3 d, f3& hitNormal, f3& point, uint32_t& mesh) {
   const uint4 tv = S.triShade[id];
   const f3 p0 = ld(S.vpos + 3 * (size_t)tv.x), p1 = ld(S.vpos + 3 * (size_t)tv.y), p2 = ld(S.vpos + 3 * (size_t)tv.z);
   float u, v, t;
   tri_test(o, d, p0, p1 - p0, p2 - p0, u, v, t, true);  // (once per vertex: the division; the same bits as the walker's)
   const float w = 1.f - u - v;
-  hitNormal = unit3(interp3(S.vnrm, tv, w, u, v));
+  hitNormal = unit3<FAST>(interp3(S.vnrm, tv, w, u, v));
   point = w * p0 + u * p1 + v * p2;
   mesh = tv.w;
 }
@@ -855,6 +857,7 @@ template <bool STATS, int LT>
 RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
                       f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
                       uint32_t* over = nullptr) {
+  constexpr bool FR = (LT & LT_FASTDET) != 0;  // 1 / length by rtd::recip_fast (see rtd::unit3)
   const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
   constexpr bool CP2 = (LT & LT_COMPACT2) != 0, CP = CP2 || (LT & LT_COMPACT) != 0;
   using VP = VpLayout<CP2 ? 2 : CP ? 1 : 0>;
@@ -889,7 +892,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
     if (bounce) {
       // (the caller's copy is read back from the pool after the loop: `point` and the bounce
       // direction do not occupy registers while the wave traverses)
-      const f3 bd = hemisphere_sample(g, hitNormal);
+      const f3 bd = hemisphere_sample<FR>(g, hitNormal);
       if (CP2) bdir = bd;  // (stays in the caller's registers)
       else fp[VP::BDIR + lane] = bd.x, fp[VP::BDIR + 64 + lane] = bd.y, fp[VP::BDIR + 128 + lane] = bd.z;
       keys[lane] = ~0ull;
@@ -1056,12 +1059,12 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   point = pt;
   if (bounce && !CP2) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
   if (alive) {
-    const BsdfBase base = bsdf_base(S.mats[mesh], hitNormal, -rayDir);  // the light-independent half, once
+    const BsdfBase base = bsdf_base<FR>(S.mats[mesh], hitNormal, -rayDir);  // the light-independent half, once
     for (uint32_t l = 0; l < nl; l++) {
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
       const f3 toLight = CP ? light_point(S.lights[l], fp[VP_DIR + (2 * l + 0) * 64 + lane], fp[VP_DIR + (2 * l + 1) * 64 + lane]) - pt
                             : mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
-      const f3 bsdf = bsdf_apply(base, toLight);
+      const f3 bsdf = bsdf_apply<FR>(base, toLight);
       const f3 radiance = light_eval(S.lights[l], pt);
       color = color + radiance * bsdf;
     }
@@ -1103,6 +1106,7 @@ template <bool STATS, int LT>
 RT_DEV f3 vertex_pool_cus(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
                           f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
                           uint32_t* ctl, uint32_t wv, int32_t waveWords, uint32_t& gen) {
+  constexpr bool FR = (LT & LT_FASTDET) != 0;  // 1 / length by rtd::recip_fast (see rtd::unit3)
   static_assert(!(LT & (LT_COMPACT2 | LT_SS | LT_WIDE)), "CU sharing: full or light-parameter pools, plain stack, binary nodes");
   const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
   constexpr bool CP = (LT & LT_COMPACT) != 0;
@@ -1132,7 +1136,7 @@ RT_DEV f3 vertex_pool_cus(const DevScene& S, bool alive, bool bounce, Rng& g, f3
       }
     }
     if (bounce) {
-      const f3 bd = hemisphere_sample(g, hitNormal);
+      const f3 bd = hemisphere_sample<FR>(g, hitNormal);
       fp[VP::BDIR + lane] = bd.x, fp[VP::BDIR + 64 + lane] = bd.y, fp[VP::BDIR + 128 + lane] = bd.z;
       keys[lane] = ~0ull;
     }
@@ -1357,12 +1361,12 @@ RT_DEV f3 vertex_pool_cus(const DevScene& S, bool alive, bool bounce, Rng& g, f3
   point = pt;
   if (bounce) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
   if (alive) {
-    const BsdfBase base = bsdf_base(S.mats[mesh], hitNormal, -rayDir);
+    const BsdfBase base = bsdf_base<FR>(S.mats[mesh], hitNormal, -rayDir);
     for (uint32_t l = 0; l < nl; l++) {
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
       const f3 toLight = CP ? light_point(S.lights[l], fp[VP_DIR + (2 * l + 0) * 64 + lane], fp[VP_DIR + (2 * l + 1) * 64 + lane]) - pt
                             : mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
-      const f3 bsdf = bsdf_apply(base, toLight);
+      const f3 bsdf = bsdf_apply<FR>(base, toLight);
       const f3 radiance = light_eval(S.lights[l], pt);
       color = color + radiance * bsdf;
     }
@@ -1431,6 +1435,7 @@ struct CuShare {  // CU-level ray sharing (vertex_pool_cus): the workgroup's con
 template <bool BRUTE, bool PHOTON, bool POOLED, bool STATS, int LT>
 RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restrict__ accum, const Lds& L, uint32_t* pool,
                         float* ex, uint32_t wave, LaneStats& st, CuShare* cu = nullptr) {
+  constexpr bool FR = (LT & LT_FASTDET) != 0;  // 1 / length by rtd::recip_fast (see rtd::unit3)
   const uint32_t lane = threadIdx.x & 63u;
   // lane = (pixel pl of the wave tile, sample slot sj): the wave integrates
   // S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side
@@ -1452,7 +1457,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
     float sx, sy;
     jitter_sample(g, (int)i, (int)A.spp, sx, sy);
     f3 o, d;
-    camera_ray(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
+    camera_ray<FR>(S.cam, ((float)px + sx) / (float)A.width, 1.f - ((float)py + sy) / (float)A.height, o, d);
     f3 c0 = mk(0.f, 0.f, 0.f), c1 = c0, c2 = c0;
     bool primary = true, alive = active;
     if constexpr (pooled) {
@@ -1469,7 +1474,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
         // (the vertex set-up is three dependent loads deep: it goes out ahead of other waves'
         // arithmetic, like the pool loop that follows; +0.4 % on C2)
         if (!(LT & LT_NOPRIO)) __builtin_amdgcn_s_setprio(1);
-        if (alive) vertex_setup_ray(S, h.id, o, d, nrm, pt, mesh);
+        if (alive) vertex_setup_ray<FR>(S, h.id, o, d, nrm, pt, mesh);
         // (Renderer.cpp:164: the hemisphere sample is drawn after every shaded vertex;
         // after the LAST one the reference draws it too but never traces it, and the
         // stream ends there — the pool only draws it when a bounce ray follows)
@@ -1500,7 +1505,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
       }
       if (wave_ballot(alive) == 0) break;
       f3 nrm = mk(0.f, 0.f, 0.f), pt = nrm, c = nrm;
-      if (alive) vertex_setup(S, h, nrm, pt);
+      if (alive) vertex_setup<FR>(S, h, nrm, pt);
       if (PHOTON) {
         if (alive) c = shade_photon<STATS>(S, A, d, h, L, nrm, pt, st);
       } else {
