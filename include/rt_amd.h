@@ -325,8 +325,9 @@ int rt_profile_collect(rt_ctx* ctx, double* total_kernel_ms, uint32_t* launches)
  *   RT_UNIT_LIGHT_SAMPLE in: state rt_light(21 f) (22 words)  out: sample3, end state
  *                        (LightSource.h:46-49 randAreaPosition from a given engine state)
  *   RT_UNIT_POW          in: double x                     out: double x^2, x^5 (Material.h:38,48 pow)
- *   RT_UNIT_RECIP        in: float x                      out: the three-instruction reciprocal, and 1.0f / x
- *                        (Ray.cpp:14's inv_det: the two must agree bit for bit for 2^-100 <= |x| <= 2^100)
+ *   RT_UNIT_RECIP        in: float x                      out: the three-instruction reciprocal, 1.0f / x, the five-
+ *                        instruction square root, sqrtf(x) (Ray.cpp:14's inv_det, Vec3.h:170-178's length: each pair
+ *                        must agree bit for bit for 2^-100 <= |x| <= 2^100)
  */
 enum {
   RT_UNIT_ASIN = 0,

@@ -501,9 +501,9 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   // (rt_kernels.hip LT_FASTDET) in two places, and the host vouches for the range here:
   //  * 1 / det of the triangle test: |det| = |e1 . (d x e2)| <= |e1| |e2| |d|; edges are at most 2 sqrt(3) maxAbs long, and
   //    the rays the RENDER kernels make are unit vectors (camera, bounce) or run from a surface point to a light sample;
-  //  * 1 / length in normalisations: a length is sqrt(float) — 0, or >= 2^-74.5 — and finite as long as no dot product
-  //    overflows: every vector the kernels normalise is a small sum of scene inputs, so |input| <= 1e17 keeps the
-  //    squares below 3.4e38.
+  //  * length and 1 / length in normalisations (sqrt_fast: the same check, 2^-100 <= x < 2^101): every vector the kernels
+  //    normalise is a small sum of scene inputs, so |input| <= 1e14 keeps the squared length below 2^100 (the lower end
+  //    is tested per lane: rt_device.h unit3).
   // Outside these bounds — or with any non-finite input — the kernels divide.  (User rays, rt_trace /
   // rt_trace_stream_device, always divide.)
   {
@@ -529,7 +529,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     }
     const double edge = 2.0 * 1.7320508 * maxAbs, dir = 1.7320508 * maxAbs + maxLight + 2.0;
     const double detBound = 1.01 * edge * edge * dir;
-    S.slowRecip = (finite && maxAny <= 1e17 && maxLight <= 1e17 && std::isfinite(detBound) && detBound < 1.2676506e30) ? 0u : 1u;
+    S.slowRecip = (finite && maxAny <= 1e14 && maxLight <= 1e14 && std::isfinite(detBound) && detBound < 1.2676506e30) ? 0u : 1u;
     if (getenv("RT_SLOW_RECIP")) S.slowRecip = 1u;  // (A/B and the parity tests of the division path)
   }
   const bool bigTree = S.n_nodes > 65536;
@@ -1053,7 +1053,7 @@ int rt_profile_collect(rt_ctx* c, double* total_ms, uint32_t* launches) {
 
 int rt_test_unit(int32_t device, uint32_t which, const void* in, void* out, uint32_t n) {
   static const uint32_t inBytes[] = {8, 4, 4, 16, 60, 68, 56, 96, 112, 88, 8, 4};
-  static const uint32_t outBytes[] = {8, 4, 4, 4, 16, 12, 24, 12, 48, 16, 16, 8};
+  static const uint32_t outBytes[] = {8, 4, 4, 4, 16, 12, 24, 12, 48, 16, 16, 16};
   if (which > RT_UNIT_RECIP) return fail(RT_ERR_INVALID, "unknown unit %u", which);
   if (n && (!in || !out)) return fail(RT_ERR_INVALID, "null argument");
   if (n == 0) return RT_OK;

@@ -48,18 +48,43 @@ RT_DEV float recip_fast(float x) {
   const float r = __builtin_amdgcn_rcpf(x);
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
+// sqrtf(x) in five instructions (v_rsq_f32, s = x y, h = y / 2, one residual correction) instead of the sixteen of the
+// correctly rounded expansion, and the SAME BITS for every x with 2^-100 <= x < 2^101 (the same exhaustive check: 0
+// mismatches; v_sqrt_f32 alone differs on 255 M inputs of that range, v_sqrt_f32 + correction on 100).
+RT_DEV float sqrt_fast(float x) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s = x * y, h = 0.5f * y;
+  return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+}
 constexpr float kRecipLo = 7.888609e-31f;  // 2^-100
 constexpr float kRecipHi = 1.2676506e30f;  // 2^100
 // Vec3.h:170-178 — null vectors stay null, otherwise multiply by 1/len.
-// FAST (a compile-time choice of the kernel instance, rt_kernels.hip LT_FASTDET): 1 / len by recip_fast.  l = sqrt(float)
-// is 0 (handled), or >= 2^-74.5 (the root of the smallest denormal), and at most 2^64 unless the dot product overflowed
-// or was NaN — which the host has excluded for the instances that say FAST (rt_api.cpp create_ctx bounds every input of
-// the scene): inside recip_fast's range, so the same bits as the division.
-template <bool FAST = false>
-RT_DEV f3 unit3(f3 a) {
+// FAST (a compile-time choice of the kernel instance, rt_kernels.hip LT_FASTDET): the length by sqrt_fast and 1 / length by
+// recip_fast where the squared length is in [2^-100, 2^100) — the upper end is the host's promise for the instances that
+// say FAST (rt_api.cpp create_ctx bounds every input of the scene by 1e14), the lower end is tested here; the length is
+// then in [2^-50, 2^50), inside recip_fast's range.  Same bits as sqrtf and the division.
+// (the general path of the FAST form, out of line: eleven inlined copies of the sqrtf + division expansions that are never
+// executed cost the big-scene instances 1 % through the instruction cache)
+__device__ __attribute__((noinline)) inline f3 unit3_general(f3 a) {
   float l = len3(a);
   if (l == 0.f) return a;
-  const float inv = FAST ? recip_fast(l) : 1.0f / l;
+  const float inv = 1.0f / l;
+  return mk(a.x * inv, a.y * inv, a.z * inv);
+}
+template <bool FAST = false>
+RT_DEV f3 unit3(f3 a) {
+  if (FAST) {
+    const float dd = dot3(a, a);
+    // (dd < 2^100 is the host's bound; below 2^-100 — a null vector, a denormal square, a NaN — the general path)
+    if (dd >= kRecipLo) {
+      const float inv = recip_fast(sqrt_fast(dd));
+      return mk(a.x * inv, a.y * inv, a.z * inv);
+    }
+    return unit3_general(a);
+  }
+  float l = len3(a);
+  if (l == 0.f) return a;
+  const float inv = 1.0f / l;
   return mk(a.x * inv, a.y * inv, a.z * inv);
 }
 RT_DEV float dist3(f3 a, f3 b) { return len3(a - b); }

@@ -1934,9 +1934,10 @@ __global__ void k_unit(uint32_t which, const void* __restrict__ in, void* __rest
       ((double*)out)[2 * (size_t)i] = rt_pow2(x), ((double*)out)[2 * (size_t)i + 1] = rt_pow5(x);
       break;
     }
-    case RT_UNIT_RECIP: {  // in: float x; out: rtd::recip_fast(x), 1.0f / x
+    case RT_UNIT_RECIP: {  // in: float x; out: rtd::recip_fast(x), 1.0f / x, rtd::sqrt_fast(x), sqrtf(x)
       const float x = ((const float*)in)[i];
-      ((float*)out)[2 * (size_t)i] = rtd::recip_fast(x), ((float*)out)[2 * (size_t)i + 1] = 1.0f / x;
+      float* o = (float*)out + 4 * (size_t)i;
+      o[0] = rtd::recip_fast(x), o[1] = 1.0f / x, o[2] = rtd::sqrt_fast(x), o[3] = __builtin_sqrtf(x);
       break;
     }
     default:

@@ -473,7 +473,7 @@ _UNIT_IO = {UNIT_ASIN: (np.float64, 1, np.float64, 1), UNIT_SINF: (np.float32, 1
             UNIT_TRIANGLE: (np.float32, 15, np.float32, 4), UNIT_BSDF: (np.float32, 17, np.float32, 3),
             UNIT_RAY_AT: (np.float32, 14, np.float32, 6), UNIT_LIGHT_EVAL: (np.float32, 24, np.float32, 3),
             UNIT_SAMPLERS: (np.uint32, 28, np.uint32, 12), UNIT_LIGHT_SAMPLE: (np.uint32, 22, np.uint32, 4),
-            UNIT_POW: (np.float64, 1, np.float64, 2), UNIT_RECIP: (np.float32, 1, np.float32, 2)}
+            UNIT_POW: (np.float64, 1, np.float64, 2), UNIT_RECIP: (np.float32, 1, np.float32, 4)}
 
 
 def unit(which, inp, out_init=None, device=0):

@@ -180,7 +180,7 @@ def test_detmath_ulp_bounds_vs_libm():
         assert (pw[:, col].astype(np.float32) != r.astype(np.float32)).mean() < 1e-6
 
 
-def test_three_instruction_reciprocal_is_the_division_bit_for_bit():
+def test_short_reciprocal_and_square_root_are_the_ieee_ones_bit_for_bit():
     """Ray.cpp:14 `inv_det = 1.0f / det`: the default render instances compute it as v_rcp_f32 + one Newton step
     (rt_device.h recip_fast).  tools/microbench/recip_exact.hip checked ALL 2^32 inputs on gfx950 (0 mismatches for
     2^-100 <= |x| < 2^101, profiles/r03_recip_exact.json); this is the regression guard: 4 M samples of that range — every
@@ -199,6 +199,12 @@ def test_three_instruction_reciprocal_is_the_division_bit_for_bit():
         want = (np.float32(1.0) / x).astype(np.float32)
     assert np.array_equal(got[:, 1].view(np.uint32), want.view(np.uint32))  # the GPU's division is IEEE's
     assert np.array_equal(got[:, 0].view(np.uint32), want.view(np.uint32))  # ... and the short form is the division
+    # the same for the five-instruction square root (rt_device.h sqrt_fast: the lengths of the normalisations)
+    pos = np.abs(x)
+    gs = pyrt.unit(pyrt.UNIT_RECIP, pos)
+    ws = np.sqrt(pos.astype(np.float32)).astype(np.float32)  # (numpy's float32 sqrt is correctly rounded)
+    assert np.array_equal(gs[:, 3].view(np.uint32), ws.view(np.uint32))
+    assert np.array_equal(gs[:, 2].view(np.uint32), ws.view(np.uint32))
 
 
 # ------------------------------------------------------------------ closest hit / any hit

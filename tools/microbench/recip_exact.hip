@@ -50,17 +50,61 @@ __global__ void k_check(unsigned long long* counts, uint32_t hiBits) {
   if (badB) atomicAdd(&counts[3 + cls], 1ull);
 }
 
+// ---- square root: __builtin_sqrtf (the correctly rounded expansion, ~16 instructions) against short forms
+__device__ __forceinline__ float sqrtV2(float x) {  // v_sqrt_f32 + residual correction through 0.5 / s
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float r = __builtin_fmaf(-s, s, x);
+  const float h = 0.5f * __builtin_amdgcn_rcpf(s);
+  return __builtin_fmaf(r, h, s);
+}
+__device__ __forceinline__ float sqrtV3(float x) {  // v_rsq_f32: s = x y, h = y / 2, one correction
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s = x * y, h = 0.5f * y;
+  const float r = __builtin_fmaf(-s, s, x);
+  return __builtin_fmaf(r, h, s);
+}
+__device__ __forceinline__ float sqrtV4(float x) {  // V3 + a second correction
+  const float y = __builtin_amdgcn_rsqf(x);
+  float s = x * y;
+  const float h = 0.5f * y;
+  float r = __builtin_fmaf(-s, s, x);
+  s = __builtin_fmaf(r, h, s);
+  r = __builtin_fmaf(-s, s, x);
+  return __builtin_fmaf(r, h, s);
+}
+// counts[8 + 4 v + cls]: v = 0 bare v_sqrt_f32, 1 V2, 2 V3, 3 V4; cls = 0: 2^-100 <= x < 2^101, 1: other positive normal, 2: the rest
+__global__ void k_check_sqrt(unsigned long long* counts, uint32_t hiBits) {
+  const uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t bits = (hiBits << 24) | lo;
+  const float x = __uint_as_float(bits);
+  const float ref = __builtin_sqrtf(x);
+  const uint32_t ex = (bits >> 23) & 255u;
+  const int cls = (bits >> 31) || ex == 0 || ex == 255 ? 2 : (ex >= 27 && ex <= 227) ? 0 : 1;
+  const float v[4] = {__builtin_amdgcn_sqrtf(x), sqrtV2(x), sqrtV3(x), sqrtV4(x)};
+  for (int k = 0; k < 4; ++k) {
+    const bool bad = ref != ref ? !(v[k] != v[k]) : __float_as_uint(v[k]) != __float_as_uint(ref);
+    if (bad) atomicAdd(&counts[8 + 4 * k + cls], 1ull);
+  }
+}
+
 int main() {
   unsigned long long* d;
-  CK(hipMalloc(&d, 8 * sizeof(unsigned long long)));
-  CK(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
+  CK(hipMalloc(&d, 32 * sizeof(unsigned long long)));
+  CK(hipMemset(d, 0, 32 * sizeof(unsigned long long)));
   for (uint32_t hi = 0; hi < 256; ++hi) hipLaunchKernelGGL(k_check, dim3(1u << 16), dim3(256), 0, nullptr, d, hi);
+  for (uint32_t hi = 0; hi < 256; ++hi) hipLaunchKernelGGL(k_check_sqrt, dim3(1u << 16), dim3(256), 0, nullptr, d, hi);
   CK(hipDeviceSynchronize());
-  unsigned long long h[8];
+  unsigned long long h[32];
   CK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
   printf("{\"inputs\": 4294967296, \"A_rcp_plus_one_newton_step\": {\"mismatch_exp_-100_to_100\": %llu, \"mismatch_other_normal\": %llu, "
          "\"mismatch_zero_denormal_inf_nan\": %llu, \"first_mismatch_bits\": \"0x%08llx\"}, "
          "\"B_plus_residual_correction\": {\"mismatch_exp_-100_to_100\": %llu, \"mismatch_other_normal\": %llu, \"mismatch_zero_denormal_inf_nan\": %llu}}\n",
          h[0], h[1], h[2], h[6], h[3], h[4], h[5]);
+  const char* names[4] = {"bare_v_sqrt_f32", "sqrt_then_residual_times_half_rcp", "rsq_one_correction", "rsq_two_corrections"};
+  printf("{\"sqrt_vs_correctly_rounded_sqrtf\": {");
+  for (int k = 0; k < 4; ++k)
+    printf("%s\"%s\": {\"mismatch_exp_-100_to_100\": %llu, \"mismatch_other_positive_normal\": %llu, \"mismatch_rest\": %llu}", k ? ", " : "", names[k],
+           h[8 + 4 * k], h[8 + 4 * k + 1], h[8 + 4 * k + 2]);
+  printf("}}\n");
   return 0;
 }
