@@ -504,6 +504,30 @@ def test_bvh_exact_on_scaled_scenes(scale, lowres):
     ctx.close()
 
 
+@pytest.mark.parametrize("scale", [1e-3, 37.0, 1e4, 1e9, 1e10, 1e15])
+def test_frames_exact_on_scaled_scenes_either_side_of_the_reciprocal_bound(scale, lowres):
+    """The default render instances take 1 / det, the lengths and 1 / length in short forms that are the IEEE operations'
+    bits only inside 2^-100 ... 2^100 (rt_device.h recip_fast / sqrt_fast); rt_create decides from the scene's magnitudes
+    whether a launch may use them (rt_api.cpp create_ctx: at the Cornell box's size x 1e9 it still may, from x 3e9 on |det|
+    is no longer bounded, from 1e14 on the inputs themselves are too large) and picks the dividing instances otherwise.
+    Whatever it picks, the frame must be the oracle's and the exhaustive loop's, bit for bit."""
+    s, _ = lowres
+    a = s.arrays()
+    f = np.float32(scale)
+    lights = a["lights"].copy()
+    lights[:, 0:3] *= f  # (rt_light: position[3] ... intensity, side at word 16)
+    lights[:, 16] *= f
+    scaled = pyrt.ArrayScene(a["pos"] * f, a["nrm"], a["tri"], a["tri_begin"], a["vtx_begin"], a["materials"], lights, a["camera"] * f)
+    ctx = pyrt.Context(scaled)
+    p = pyrt.make_params(32, 32, 3, seed=13)
+    _, acc, st = ctx.render(p)
+    _, brute, _ = ctx.render(pyrt.make_params(32, 32, 3, seed=13, accel=pyrt.ACCEL_BRUTE))
+    _, ref, rst = orc.render(scaled, p, math_mode=orc.MATH_DET)
+    assert np.array_equal(bits(acc), bits(brute))
+    assert np.array_equal(bits(acc), bits(ref)) and (st.rays_closest, st.rays_shadow) == (rst.rays_closest, rst.rays_shadow)
+    ctx.close()
+
+
 def test_degenerate_inputs_are_rejected_or_harmless():
     s = pyrt.Scene("cubes", 16, 16)
     a = s.arrays()
