@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -531,6 +532,29 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     const double detBound = 1.01 * edge * edge * dir;
     S.slowRecip = (finite && maxAny <= 1e14 && maxLight <= 1e14 && std::isfinite(detBound) && detBound < 1.2676506e30) ? 0u : 1u;
     if (getenv("RT_SLOW_RECIP")) S.slowRecip = 1u;  // (A/B and the parity tests of the division path)
+    // ... and the device vouches for the short forms itself, once per process and device (2^25 inputs, well under a
+    // millisecond): the exhaustive check ran on one MI355X; a part whose v_rcp_f32 / v_rsq_f32 rounded differently would
+    // show here, and its contexts divide.
+    if (!S.slowRecip) {
+      static std::mutex mu;
+      static std::map<int, bool> verified;
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = verified.find(c->device);
+      if (it == verified.end()) {
+        bool ok = false;
+        uint32_t* dBad = nullptr;
+        uint32_t bad = 1u;
+        if (hipMalloc(reinterpret_cast<void**>(&dBad), sizeof(uint32_t)) == hipSuccess) {
+          if (hipMemset(dBad, 0, sizeof(uint32_t)) == hipSuccess && rtk::launch_selfcheck_recip(dBad, nullptr) == hipSuccess &&
+              hipMemcpy(&bad, dBad, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess)
+            ok = bad == 0u;
+          (void)hipFree(dBad);
+        }
+        it = verified.emplace(c->device, ok).first;
+        if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "short reciprocal / square root self-check on device %d: %s\n", c->device, ok ? "bit-identical" : "MISMATCH, dividing");
+      }
+      if (!it->second) S.slowRecip = 1u;
+    }
   }
   const bool bigTree = S.n_nodes > 65536;
   S.leafT = getenv("RT_LEAFT") ? atoi(getenv("RT_LEAFT")) : bigTree ? 32 : 12;

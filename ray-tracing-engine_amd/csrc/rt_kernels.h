@@ -126,5 +126,7 @@ hipError_t launch_kd_build(float4* items, uint32_t n, int depthOverride, hipStre
 hipError_t launch_photon_gather(const float4* items, const float4* slotDir, uint32_t n, float4* phPos, float4* phDir,
                                 uint32_t* perm, hipStream_t stream);
 hipError_t launch_unit(uint32_t which, const void* in, void* out, uint32_t n, hipStream_t stream);
+// *dBad (zeroed by the caller) != 0 afterwards: rtd::recip_fast / sqrt_fast differ from the division / sqrtf on this device
+hipError_t launch_selfcheck_recip(uint32_t* dBad, hipStream_t stream);
 
 }  // namespace rtk

@@ -2237,6 +2237,23 @@ hipError_t launch_emit(const DevScene& S, uint32_t perLight, uint32_t seed, floa
   return hipGetLastError();
 }
 
+// recip_fast / sqrt_fast against the division and sqrtf on THIS device: every mantissa (2^23) in two neighbouring
+// binades (both signs for the reciprocal) — v_rcp_f32 and v_rsq_f32 work on the mantissa and the exponent's parity, and
+// scaling by powers of four is exact on both sides of the comparison away from the denormals, so this covers what the
+// exhaustive check of tools/microbench/recip_exact.hip found to be the whole in-range behaviour.  *bad != 0: a mismatch.
+__global__ void k_selfcheck_recip(uint32_t* bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 2^25: sign | binade | mantissa
+  const uint32_t bits = ((i >> 24) << 31) | ((127u + ((i >> 23) & 1u)) << 23) | (i & 0x7fffffu);
+  const float x = __uint_as_float(bits);
+  bool ok = __float_as_uint(rtd::recip_fast(x)) == __float_as_uint(1.0f / x);
+  if (!(i >> 24)) ok = ok && __float_as_uint(rtd::sqrt_fast(x)) == __float_as_uint(__builtin_sqrtf(x));
+  if (!ok) atomicOr(bad, 1u);
+}
+hipError_t launch_selfcheck_recip(uint32_t* dBad, hipStream_t stream) {
+  hipLaunchKernelGGL(k_selfcheck_recip, dim3(1u << 17), dim3(256), 0, stream, dBad);
+  return hipGetLastError();
+}
+
 hipError_t launch_unit(uint32_t which, const void* in, void* out, uint32_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_unit, dim3((n + 255) / 256), dim3(256), 0, stream, which, in, out, n);
