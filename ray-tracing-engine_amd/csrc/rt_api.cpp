@@ -316,7 +316,15 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   const int e = c->evUsed % kEventPairs;
   // rt_params.reserved[2] bit 0: the queue-based (wavefront) integrator — BVH direct lighting with
   // at most 3 lights, like the pooled kernel; same frame bit for bit
-  if ((p->reserved[2] & 1u) && !p->use_photons && p->accel != RT_ACCEL_BRUTE && c->S.n_lights <= 3u) {
+  // RT_PHOTON_STREAM=1 (opt-in): photon-map shading in ray mode (BASELINE config 3) as a QUERY STREAM
+  // (wavefront_kernels.h k_knn_stream: lanes that finish their k-NN walk take the next query instead of waiting for the
+  // slowest of 64).  Same frame bit for bit — and 2 x SLOWER (28.5 against 14.3 ms: DESIGN.md section 4.6): lanes that
+  // start their walks at different times are in different branches of the walk at every step, and a wave pays for
+  // every branch any of its lanes is in (VALU lane utilisation 0.29 against 0.58).  Not with counters (the fused kernel
+  // owns the node / kd-visit counters).
+  static const bool photonStreamOn = getenv("RT_PHOTON_STREAM") && atoi(getenv("RT_PHOTON_STREAM")) != 0;
+  const bool photonStream = photonStreamOn && p->use_photons && p->mode == RT_MODE_RAY && p->accel != RT_ACCEL_BRUTE && !p->collect_stats;
+  if (photonStream || ((p->reserved[2] & 1u) && !p->use_photons && p->accel != RT_ACCEL_BRUTE && c->S.n_lights <= 3u)) {
     rt_ctx::GranList G;
     rc = ensure_granules(c, p, p->rank, &G);
     if (rc != RT_OK) return rc;
@@ -334,8 +342,8 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
     if (P > c->wfCap) {
       if (c->wfBlock) HIP_TRY(hipFree(c->wfBlock));
       c->wfBlock = nullptr, c->wfCap = 0;
-      // rng 4, org 16, dir 16, key 8, nrm 16, pnt 16, col 48, rayO 64, rayD 64, res 32 = 284 B per path
-      const size_t bytes = P * 284 + 4096 + 2048 * sizeof(unsigned long long);
+      // rng 4, org 16, dir 16, key 8, nrm 16, pnt 16, knn 16, col 48, rayO 64, rayD 64, res 32 = 300 B per path
+      const size_t bytes = P * 300 + 4096 + 2048 * sizeof(unsigned long long);
       HIP_TRY(hipMalloc(&c->wfBlock, bytes));
       char* q = static_cast<char*>(c->wfBlock);
       auto take = [&](size_t n) {
@@ -348,6 +356,7 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
       W.col = reinterpret_cast<float4*>(take(P * 48));
       W.org = reinterpret_cast<float4*>(take(P * 16)), W.dir = reinterpret_cast<float4*>(take(P * 16));
       W.nrm = reinterpret_cast<float4*>(take(P * 16)), W.pnt = reinterpret_cast<float4*>(take(P * 16));
+      W.knn = reinterpret_cast<float4*>(take(P * 16));
       W.res = reinterpret_cast<uint2*>(take(P * 32)), W.key = reinterpret_cast<uint2*>(take(P * 8));
       W.rng = reinterpret_cast<uint32_t*>(take(P * 4));
       W.stripes = reinterpret_cast<unsigned long long*>(take(2048 * sizeof(unsigned long long)));
@@ -358,8 +367,10 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
     W.gran = G.d, W.nGran = G.n, W.width = p->width, W.height = p->height, W.spp = p->spp, W.seed = p->seed;
     W.s0 = A.s0, W.s1 = A.s1, W.batch = (uint32_t)batch, W.nPaths = 0;
     HIP_TRY(hipEventRecord(c->ev[e][0], stream));
-    hipError_t hw = rtk::launch_wavefront(c->S, W, p->mode, p->max_depth, dAccum, c->dCounters, c->dTileCounter, A.stackLevels,
-                                          c->numCUs, stream);
+    hipError_t hw = photonStream ? rtk::launch_wavefront_photon(c->S, W, p->k, p->photons_requested, dAccum, c->dCounters, c->dTileCounter,
+                                                                c->numCUs, stream)
+                                 : rtk::launch_wavefront(c->S, W, p->mode, p->max_depth, dAccum, c->dCounters, c->dTileCounter, A.stackLevels,
+                                                         c->numCUs, stream);
     if (hw != hipSuccess) return fail(RT_ERR_HIP, "wavefront launch failed: %s", hipGetErrorString(hw));
     HIP_TRY(hipEventRecord(c->ev[e][1], stream));
     c->evUsed++;

@@ -89,6 +89,7 @@ struct WfArgs {
   float4 *org, *dir;     // [P] current ray
   uint2* key;            // [P] current hit {t bits, triangle id}; {~0, ~0}: the path has ended
   float4 *nrm, *pnt;     // [P] vertex normal (+ mesh in w), point
+  float4* knn;           // [P] photon-map shading: {sum of the k photon directions, distance of the k-th} (k_knn_stream)
   float4* col;           // [3][P] vertex colours; col[0].w: primary hit, col[1].w: slot holds a sample
   float4 *rayO, *rayD;   // [4P] ray queue
   uint2* res;            // [4P] results
@@ -97,6 +98,8 @@ struct WfArgs {
 hipError_t launch_wavefront(const DevScene& S, const WfArgs& W, uint32_t mode, uint32_t maxDepth, float4* accum,
                             unsigned long long* counters, uint32_t* queueCounter, uint32_t stackLevels, uint32_t numCUs,
                             hipStream_t stream);
+hipError_t launch_wavefront_photon(const DevScene& S, const WfArgs& W, uint32_t k, uint32_t photonsRequested, float4* accum,
+                                   unsigned long long* counters, uint32_t* queueCounter, uint32_t numCUs, hipStream_t stream);
 // ray queue in HBM -> results (wavefront stage T)
 hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const float4* rayD, uint32_t n, uint2* res,
                                uint32_t* counter, uint32_t stackLevels, uint32_t numCUs, hipStream_t stream);
