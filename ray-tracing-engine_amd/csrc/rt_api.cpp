@@ -166,6 +166,12 @@ uint32_t choose_sshift(const rt_ctx* c, const rt_params* p, uint32_t spp_count) 
     const uint32_t want = c->S.n_nodes > 65536u ? 6u : 4u;
     while (s < want && (2u << s) <= spp_count) ++s;
   }
+  // Photon-map shading: the k-NN walks of a pixel's samples run almost in step (their queries lie within one pixel's
+  // footprint), and a wave issues every branch any of its lanes is in — C3 at 1 / 2 / 4 / 8 / 16 samples of a pixel per
+  // wave: 26.3 / 19.6 / 15.7 / 13.7 / 12.4 ms (16 was 17.0 ms until the waves' counts went to striped slots:
+  // rt_kernels.hip flush_stats_striped); at 64 spp, 16 / 32 / 64: 46.6 / 43.9 / 42.8 ms (profiles/r03_c3_samples_per_wave.txt)
+  if (p->use_photons && p->accel != RT_ACCEL_BRUTE)
+    while (s < 6u && (2u << s) <= spp_count) ++s;
   return s;
 }
 
@@ -311,7 +317,7 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   A.stackLevels = (levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels) + 1u;
   // the wide tree: its own stack need + the sentinel row + the two rows a step writes ahead of the top
   A.stackLevelsWide = (c->bvh.stackNeed4 > 1 ? c->bvh.stackNeed4 : 1u) + 3u;
-  A.tileCounter = c->dTileCounter, A.numCUs = c->numCUs, A.waveWords = 0;
+  A.tileCounter = c->dTileCounter, A.numCUs = c->numCUs, A.waveWords = 0, A.tilesPerBlock = 1;
   A.ssOver = c->dSsOver;
   const int e = c->evUsed % kEventPairs;
   // rt_params.reserved[2] bit 0: the queue-based (wavefront) integrator — BVH direct lighting with
@@ -596,8 +602,9 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
       return fail(RT_ERR_HIP, "short-stack overflow allocation failed");
     }
   }
-  if (hipMalloc(reinterpret_cast<void**>(&c->dCounters), RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(c->dCounters, 0, RTK_CNT_COUNT * sizeof(unsigned long long)) != hipSuccess) {
+  // (the counter block + 1,024 striped slots x 4 for the one-wave-per-workgroup kernels: rt_kernels.hip flush_stats_striped)
+  if (hipMalloc(reinterpret_cast<void**>(&c->dCounters), (RTK_CNT_COUNT + 4096) * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->dCounters, 0, (RTK_CNT_COUNT + 4096) * sizeof(unsigned long long)) != hipSuccess) {
     rt_destroy(c);
     return fail(RT_ERR_HIP, "counter allocation failed");
   }

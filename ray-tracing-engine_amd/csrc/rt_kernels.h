@@ -67,6 +67,7 @@ struct RenderArgs {
   uint32_t stackLevelsWide;  // the same for the wide tree (its stack need + the sentinel row + 2 rows the step writes ahead)
   uint32_t sshift;        // a wave = (64 >> sshift) pixels x (1 << sshift) samples side by side
   uint32_t tileW, tileH;  // pixel footprint of one wave (tileW * tileH == 64 >> sshift)
+  uint32_t tilesPerBlock; // one-wave-per-workgroup kernels (k_render): consecutive wave tiles a workgroup renders (launcher)
   // persistent pooled kernel (k_render_persist)
   uint32_t* tileCounter;  // next wave tile to hand out (zeroed before the launch)
   uint32_t waveWords;     // LDS words per wave (stack levels x 64 + pool), set by the launcher

@@ -1522,6 +1522,37 @@ RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool 
   }
 }
 
+// The same for the one-wave-per-workgroup kernels, whose frames have up to hundreds of thousands of waves: the three
+// ray / query counts go to 1,024 striped slots behind the counter block (counters + RTK_CNT_COUNT: [1024][4]) and
+// k_fold_stripes adds them up after the kernel — 262 k waves adding to ONE address each spent 4 of the photon frame's
+// 17 ms queueing at the memory side (same-address atomics serialise there).
+RT_DEV void flush_stats_striped(const LaneStats& st, unsigned long long* counters) {
+  const uint32_t c = wave_sum(st.closest), s = wave_sum(st.shadow), q = wave_sum(st.knn);
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* stripe = counters + RTK_CNT_COUNT + 4u * (blockIdx.x & 1023u);
+    if (c) atomicAdd(&stripe[0], (unsigned long long)c);
+    if (s) atomicAdd(&stripe[1], (unsigned long long)s);
+    if (q) atomicAdd(&stripe[2], (unsigned long long)q);
+  }
+}
+__global__ __launch_bounds__(1024) void k_fold_stripes(unsigned long long* __restrict__ counters) {
+  __shared__ unsigned long long sh[3][16];
+  unsigned long long* stripe = counters + RTK_CNT_COUNT + 4u * threadIdx.x;
+  unsigned long long v[3] = {stripe[0], stripe[1], stripe[2]};
+  stripe[0] = stripe[1] = stripe[2] = 0;  // ready for the next launch
+  for (int j = 0; j < 3; ++j) {
+    for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
+    if ((threadIdx.x & 63u) == 0) sh[j][threadIdx.x >> 6] = v[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 16; i++) t += sh[threadIdx.x][i];
+    const int which = threadIdx.x == 0 ? RTK_CNT_CLOSEST : threadIdx.x == 1 ? RTK_CNT_SHADOW : RTK_CNT_KNN;
+    if (t) atomicAdd(&counters[which], t);
+  }
+}
+
 // [levels][64] stack, then (photon variants) [k][64] heap distances and [k][64] heap ids
 template <bool PHOTON>
 RT_DEV Lds carve_lds(uint32_t* base, uint32_t levels = STACK, uint32_t kslots = KMAX) {
@@ -1679,8 +1710,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
   // levels — both idle when a sample is handed over
   float* ex = reinterpret_cast<float*>(POOLED ? pool : lds);
   LaneStats st;
-  if (blockIdx.x < A.n_tiles) render_tile<BRUTE, PHOTON, POOLED, STATS, LT_NONE>(S, A, accum, L, pool, ex, blockIdx.x, st);
-  flush_stats(st, counters, STATS);
+  // A.tilesPerBlock consecutive wave tiles per workgroup (1 unless RT_TILES_PER_BLOCK says otherwise: more of them
+  // unbalance the grid — C3 13.7 / 14.8 / 17.8 ms at 4 / 8 / 16)
+  const uint32_t t0 = blockIdx.x * A.tilesPerBlock, t1 = min(A.n_tiles, t0 + A.tilesPerBlock);
+  for (uint32_t t = t0; t < t1; ++t) render_tile<BRUTE, PHOTON, POOLED, STATS, LT_NONE>(S, A, accum, L, pool, ex, t, st);
+  if (STATS) flush_stats(st, counters, true);
+  else flush_stats_striped(st, counters);  // (launch_render2 folds the stripes)
 }
 
 // The pooled integrator as PERSISTENT workgroups: one workgroup of up to 16 waves per CU
@@ -2250,10 +2285,17 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   }
   const uint32_t rows = A.stackLevels + (PHOTON ? 2 * A.k : 0);
   const size_t ldsBytes = 4u * ((rows < 4u ? 4u : rows) * BLOCK + (POOLED ? VP_WORDS : 0));
+  RenderArgs A1 = A;
+  static const int tpbEnv = getenv("RT_TILES_PER_BLOCK") ? atoi(getenv("RT_TILES_PER_BLOCK")) : 0;
+  A1.tilesPerBlock = tpbEnv > 0 ? (uint32_t)tpbEnv : 1u;
+  const uint32_t nBlocks = (blocks + A1.tilesPerBlock - 1u) / A1.tilesPerBlock;
   // Occupancy target (waves per SIMD) of the one-wave-per-workgroup kernels.
   constexpr int MINW = PHOTON ? 2 : 4;
-  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, true, 1>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
-  else hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, false, MINW>), dim3(blocks), dim3(BLOCK), ldsBytes, stream, S, A, accum, counters);
+  if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, true, 1>), dim3(nBlocks), dim3(BLOCK), ldsBytes, stream, S, A1, accum, counters);
+  else {
+    hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, false, MINW>), dim3(nBlocks), dim3(BLOCK), ldsBytes, stream, S, A1, accum, counters);
+    hipLaunchKernelGGL(k_fold_stripes, dim3(1), dim3(1024), 0, stream, counters);
+  }
   return hipGetLastError();
 }
 
