@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 enum {
   RT_OK = 0,
@@ -90,14 +90,15 @@ typedef struct rt_options {
   uint32_t bvh_builder;    /* RT_BVH_HOST (SAH, host threads) | RT_BVH_DEVICE (Morton-
                               order SAH on the GPU, csrc/bvh_gpu.hip); the environment
                               variable RT_BVH_GPU=1 selects the device builder too      */
-  uint32_t bvh_width;      /* children per node record the render / trace kernels traverse:
-                              0 or 2 = binary (32-B records, the default), 4 = the collapsed
-                              4-wide form (64-B records; RT_BVH_WIDE=1 selects it too).  Same
-                              hits either way; host-built trees only.  Opt-in: fewer node
-                              visits but more vector-memory requests, slower on MI355X        */
+  uint32_t node_format;    /* RT_NODES_*: the node records the pooled render kernel and rt_trace
+                              traverse.  AUTO picks per scene; the hits are the same either way  */
   uint32_t reserved[4];
 } rt_options;
 enum { RT_BVH_HOST = 0, RT_BVH_DEVICE = 1 };
+/* RT_NODES_F16: 32-byte records, 12 binary16 box planes + 2 child refs (two 16-byte requests per visit).
+ * RT_NODES_Q8:  16-byte records, 12 8-bit box planes in the frame of the record's 16-KiB block + one
+ *               packed child word (ONE request per visit), nodes and triangle records in one array.   */
+enum { RT_NODES_AUTO = 0, RT_NODES_F16 = 1, RT_NODES_Q8 = 2 };
 
 typedef struct rt_params {
   uint32_t width, height;
@@ -129,10 +130,10 @@ typedef struct rt_stats {
   uint64_t rays_closest;   /* closest-hit casts (primary + bounce)              */
   uint64_t rays_shadow;    /* any-hit casts                                     */
   uint64_t knn_queries;
-  uint64_t nodes_visited;  /* BVH node records fetched (collect_stats): 32-B binary records, or
-                              64-B records when rt_bvh_info.n_wide_nodes > 0            */
+  uint64_t nodes_visited;  /* BVH node records fetched (collect_stats)          */
   uint64_t tris_tested;    /* 48-B triangle records tested (collect_stats)      */
   uint64_t kd_visited;     /* kd-tree nodes visited (collect_stats)             */
+  uint64_t frame_fetches;  /* RT_NODES_Q8: block frames fetched (collect_stats) */
   double kernel_ms;        /* device time of the integrate kernel(s)            */
   uint64_t reserved[4];
 } rt_stats;
@@ -155,7 +156,7 @@ typedef struct rt_bvh_info {
   float pad;           /* absolute box padding used                             */
   float build_ms;      /* wall time of the build inside rt_create                */
   uint32_t builder;    /* RT_BVH_HOST / RT_BVH_DEVICE                            */
-  uint32_t n_wide_nodes; /* > 0: the kernels traverse the 4-wide form (that many 64-B records) */
+  uint32_t node_format;  /* RT_NODES_F16 / RT_NODES_Q8: what the pooled render kernel traverses */
 } rt_bvh_info;
 
 typedef struct rt_ctx rt_ctx;
@@ -273,14 +274,15 @@ int rt_bvh_export(rt_ctx* ctx, void* nodes64 /*n_nodes*64 B*/, void* tris48 /*n_
  * digest must not depend on it.  (No reference counterpart: BVH.h:100-161 is dead code.) */
 int rt_bvh_build_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t threads, rt_bvh_info* info,
                       uint64_t* digest, double* seconds);
-/* The wide (4-ary) form of the host-built tree alone (no GPU): builds, collapses with the given
- * stack budget (0 = the binary tree's depth) and CHECKS the result — every triangle record reachable
- * exactly once, every stored child box containing its padded geometry, unused slots inert, the stack
- * need as reported and within the budget.  out8 = {binary nodes, wide nodes, stack need, binary
- * depth, nodes with 4 / 3 / 2 children, 0}; est2 (optional) = surface-area estimate of node visits per
- * random ray, binary / wide.  (No reference counterpart: BVH.h is dead code there.) */
-int rt_bvh_wide_check_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t stack_budget, uint32_t* out8,
-                           double* est2);
+/* The host-built tree in the given device node format alone (no GPU): builds, packs and CHECKS the
+ * result — every node reachable exactly once, every triangle record exactly once, every stored child box
+ * containing its padded geometry, the depth as reported and within the cap.  node_format: RT_NODES_F16 or
+ * RT_NODES_Q8.  out8 = {nodes, Q8: 16-byte slots of the unified array, Q8: blocks, depth, Q8: nodes the
+ * packer had to add (leaf wrappers), 0, 0, 0}; est2 (optional) = surface-area estimate of node visits per
+ * random ray from the float boxes / from the decoded boxes of the format.  (No reference counterpart: BVH.h
+ * is dead code there.) */
+int rt_bvh_check_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t node_format, uint32_t* out8,
+                      double* est2);
 /* Measured-cost tuning of the host-built BVH (no counterpart in the reference, whose rayTrace is the exhaustive
  * loop of RayTracer.h:27-53; this only changes HOW FAST the same hits are found).  Every tree over the same leaves
  * returns the same hits, so a probe frame traces exactly the same rays whatever the tree and its counters are a

@@ -399,17 +399,15 @@ struct Rotator {
 };
 
 
-// ---------------------------------------------------------------- subtree reinsertion
-// The second post-pass (after Bittner, Hapala, Havran: "Fast insertion-based optimization of bounding
-// volume hierarchies", 2013, restated): a subtree L is taken out of the tree (its parent goes with it, its
-// sibling moves up) and put back at the position X — any node of the tree — where "a new node over X and L"
-// adds the least surface area to the tree: area(X u L) for the new node plus what the ancestors of X grow
-// by.  A branch-and-bound search from the root finds X (the induced growth only increases on the way down,
-// so a branch is cut as soon as it alone exceeds the best total found).  Rotations only see moves between
-// a node and its grandchildren; this one moves a subtree across the whole tree, which is what a top-down
-// SAH build cannot undo: a split made with the information of its level only.  The depth cap is enforced
-// (a position that would push a leaf below it is not a candidate), the leaves themselves never change, and
-// the procedure is deterministic (fixed order, no threads).
+// ---------------------------------------------------------------- subtree moves (the measured-cost tuner's proposals)
+// After Bittner, Hapala, Havran: "Fast insertion-based optimization of bounding volume hierarchies", 2013, restated:
+// a subtree L is taken out of the tree (its parent goes with it, its sibling moves up) and can be put back at any
+// position X as "a new node over X and L"; a branch-and-bound search from the root lists the positions that add the
+// least surface area (the induced growth only increases on the way down).  The depth cap is enforced (a position
+// that would push a leaf below it is not a candidate) and the leaves never change.  Round 3 ran whole passes of
+// this by area alone (-6.2 / -2.3 / -0.4 % inner surface, +1.0 / +1.6 / +0.2 % node visits of the renderer's rays:
+// profiles/r03_reinsertion_ab.txt — the surface-area estimate no longer predicts visits at that level); the passes
+// are gone, tuneMeasured below uses the moves with a MEASURED cost.
 struct Reinserter {
   struct Item {
     Box box;
@@ -420,7 +418,6 @@ struct Reinserter {
   std::vector<Item> it;
   int depthCap;
   uint32_t nInner = 0;
-  uint64_t moves = 0;
 
   void load(const std::vector<Node>& nodes) {
     nInner = (uint32_t)nodes.size();
@@ -479,12 +476,6 @@ struct Reinserter {
       if (same) break;
       G.box = b, G.height = h;
     }
-  }
-
-  double innerArea() const {
-    double s = 0;
-    for (uint32_t i = 0; i < nInner; ++i) s += it[i].box.halfArea();
-    return s;
   }
 
   struct Cand {
@@ -575,38 +566,6 @@ struct Reinserter {
         }
       }
     }
-  }
-  int32_t search(int32_t l, int32_t exclude, float& bestOut) {
-    std::vector<Pos> one;
-    searchK(l, exclude, 1, one);
-    bestOut = one.empty() ? std::numeric_limits<float>::infinity() : one[0].cost;
-    return one.empty() ? -1 : one[0].item;
-  }
-
-  // true if L was moved
-  bool reinsert(int32_t l) {
-    if (it[l].parent <= 0) return false;  // the root's children stay (the root is never re-created)
-    const int32_t s = takeOut(l);
-    float best;
-    int32_t x = search(l, -1, best);
-    // the old position, priced the same way: a move must be a strict gain (no wandering between equal positions)
-    if (x < 0 || !(best < costAt(s, it[l].box) * (1.f - 1e-6f))) x = s;
-    putBack(l, x);
-    if (x != s) ++moves;
-    return x != s;
-  }
-
-  // one pass: every subtree whose box is at least `minFrac` of the root's, largest first
-  void pass(float minFrac) {
-    std::vector<std::pair<float, int32_t>> order;
-    const float rootA = it[0].box.halfArea();
-    for (int32_t i = 1; i < (int32_t)it.size(); ++i)
-      if (it[i].parent > 0) {
-        const float a = it[it[i].parent].box.halfArea();  // what a badly placed subtree inflates is its parent
-        if (a >= minFrac * rootA) order.push_back({a, i});
-      }
-    std::sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
-    for (const auto& o : order) reinsert(o.second);
   }
 };
 
@@ -797,136 +756,6 @@ static void relayoutTop(std::vector<Node>& nodes, uint32_t kTop) {
   nodes.swap(out);
 }
 
-// ---------------------------------------------------------------- wide (4-ary) form
-namespace {
-struct Collapser {
-  Built& b;
-  std::vector<Node4x16>& out;
-  std::vector<uint8_t> height;  // stack entries the BINARY subtree below a node can need (a node over two leaves: 1)
-  uint32_t maxNeed = 0;
-  double rootArea = 0;
-
-  struct Cand {
-    int32_t ref;
-    float lo[3], hi[3];
-    float area() const {
-      const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-      return dx * dy + dy * dz + dz * dx;
-    }
-  };
-  static Cand childOf(const Node& n, int i) {
-    Cand c;
-    c.ref = n.child[i];
-    for (int a = 0; a < 3; ++a) c.lo[a] = i ? n.lo1[a] : n.lo0[a], c.hi[a] = i ? n.hi1[a] : n.hi0[a];
-    return c;
-  }
-  int need(int32_t ref) const { return ref < 0 ? 0 : height[ref]; }
-
-  void computeHeights() {
-    height.assign(b.nodes.size(), 0);
-    // children may sit before or after their parent (relayoutTop): explicit post-order
-    std::vector<std::pair<int32_t, int>> st;
-    st.push_back({0, 0});
-    while (!st.empty()) {
-      auto& top = st.back();
-      const Node& nd = b.nodes[top.first];
-      if (top.second < 2) {
-        const int32_t c = nd.child[top.second++];
-        if (c >= 0) st.push_back({c, 0});
-      } else {
-        height[top.first] = (uint8_t)(1 + std::max(need(nd.child[0]), need(nd.child[1])));
-        st.pop_back();
-      }
-    }
-  }
-
-  // emits the wide node that replaces binary node `idx`; `budget` = stack entries still available
-  // to this subtree, `used` = entries already on the stack when a ray arrives here
-  uint32_t emit(int32_t idx, int budget, int used, double pHere) {
-    Cand c[4];
-    int k = 2;
-    c[0] = childOf(b.nodes[idx], 0), c[1] = childOf(b.nodes[idx], 1);
-    while (k < 4) {
-      int pick = -1;
-      float bestA = -1.f;
-      for (int i = 0; i < k; ++i) {
-        if (c[i].ref < 0) continue;
-        // with k + 1 children a visit pushes up to k entries: every child's own need must still fit
-        bool ok = true;
-        for (int j = 0; j < k && ok; ++j)
-          if (j != i) ok = k + need(c[j].ref) <= budget;
-        const Node& g = b.nodes[c[i].ref];
-        ok = ok && k + need(g.child[0]) <= budget && k + need(g.child[1]) <= budget;
-        if (ok && c[i].area() > bestA) bestA = c[i].area(), pick = i;
-      }
-      if (pick < 0) break;
-      const Node& g = b.nodes[c[pick].ref];
-      c[pick] = childOf(g, 0);
-      c[k++] = childOf(g, 1);
-    }
-    const uint32_t self = (uint32_t)out.size();
-    out.emplace_back();
-    maxNeed = std::max<uint32_t>(maxNeed, (uint32_t)(used + k - 1));
-    b.visitCost4 += pHere;
-    int32_t refs[4];
-    for (int i = 0; i < k; ++i) {
-      if (c[i].ref >= 0) {
-        const double pc = rootArea > 0 ? std::min(1.0, (double)c[i].area() / rootArea) : 1.0;
-        const uint32_t w = emit(c[i].ref, budget - (k - 1), used + k - 1, pc);
-        if (w >= (1u << 25)) throw std::runtime_error("wide node offsets exceed 31 bits");
-        refs[i] = (int32_t)(w * 64u);
-      } else {
-        const uint32_t code = ~(uint32_t)c[i].ref;
-        refs[i] = (int32_t)~((code >> 3) * 48u | (code & 7u));
-      }
-    }
-    Node4x16& q = out[self];
-    for (int i = 0; i < 4; ++i) {
-      if (i < k) {
-        for (int a = 0; a < 3; ++a) {
-          q.box[i][2 * a] = toHalfDirected(c[i].lo[a] * b.boxScale, false);
-          q.box[i][2 * a + 1] = toHalfDirected(c[i].hi[a] * b.boxScale, true);
-          if (halfToFloat(q.box[i][2 * a]) > c[i].lo[a] * b.boxScale || halfToFloat(q.box[i][2 * a + 1]) < c[i].hi[a] * b.boxScale)
-            throw std::runtime_error("internal error: packed wide box does not contain the float box");
-        }
-        q.child[i] = refs[i];
-      } else {
-        for (int a = 0; a < 3; ++a) q.box[i][2 * a] = 0x7bffu, q.box[i][2 * a + 1] = 0xfbffu;  // +65504 / -65504
-        q.child[i] = refs[0];
-      }
-    }
-    return self;
-  }
-};
-}  // namespace
-
-void collapse4(Built& b, uint32_t stackBudget) {
-  b.nodes4.clear(), b.stackNeed4 = 0, b.visitCost2 = b.visitCost4 = 0;
-  if (b.nodes.empty()) return;
-  Collapser C{b, b.nodes4};
-  C.computeHeights();
-  {
-    Box r;
-    r.reset();
-    const Node& n0 = b.nodes[0];
-    r.grow(n0.lo0), r.grow(n0.hi0), r.grow(n0.lo1), r.grow(n0.hi1);
-    C.rootArea = r.halfArea();
-  }
-  const int budget = std::max<int>(C.height[0], (int)stackBudget);
-  if (budget + 3 > kMaxDepth + 8) throw std::runtime_error("wide BVH stack budget out of range");
-  b.nodes4.reserve(b.nodes.size() / 2 + 16);
-  C.emit(0, budget, 0, 1.0);
-  b.stackNeed4 = C.maxNeed;
-  // the binary tree's estimate of node visits per random ray, for the report: the root plus every
-  // inner child by its box area
-  double v2 = 1.0;
-  for (const Node& n : b.nodes)
-    for (int i = 0; i < 2; ++i)
-      if (n.child[i] >= 0) v2 += std::min(1.0, (double)Collapser::childOf(n, i).area() / std::max(C.rootArea, 1e-300));
-  b.visitCost2 = v2;
-}
-
-
 // Child 0 = the child with the SMALLER box: any-hit rays of the big-scene kernels enter it first (rt_kernels.hip
 // Trav::round); closest-hit traversal orders by entry distance and does not care.
 static void smallerChildFirst(std::vector<Node>& nodes) {
@@ -1063,6 +892,275 @@ void packNodes(Built& out) {
   }
 }
 
+// RT_BVH_VERBOSE: what the 8-bit frames cost in box surface, by tree level
+static void reportQ8(const Built& b) {
+  std::vector<double> aF(64, 0.0), aQ(64, 0.0);
+  std::vector<uint32_t> cnt(64, 0);
+  struct E { int32_t node; uint32_t off; int lvl; };
+  std::vector<E> st{{0, kQ8RootOffset, 0}};
+  while (!st.empty()) {
+    const E e = st.back();
+    st.pop_back();
+    float lo[2][3], hi[2][3];
+    int32_t ch[2];
+    decodeQ8(b, e.off, lo, hi, ch);
+    const Node& nd = b.nodes[e.node];
+    for (int c = 0; c < 2; ++c) {
+      const float* fl = c ? nd.lo1 : nd.lo0;
+      const float* fh = c ? nd.hi1 : nd.hi0;
+      const double x = (double)fh[0] - fl[0], y = (double)fh[1] - fl[1], z = (double)fh[2] - fl[2];
+      const double X = (double)hi[c][0] - lo[c][0], Y = (double)hi[c][1] - lo[c][1], Z = (double)hi[c][2] - lo[c][2];
+      aF[e.lvl] += x * y + y * z + z * x, aQ[e.lvl] += X * Y + Y * Z + Z * X, cnt[e.lvl]++;
+      if (nd.child[c] >= 0) st.push_back({nd.child[c], (uint32_t)ch[c], e.lvl + 1});
+    }
+  }
+  for (int l = 0; l < 64; ++l)
+    if (cnt[l]) fprintf(stderr, "Q8 level %2d: %8u child boxes, area float %.6g, decoded %.6g (+%.2f %%)\n", l, cnt[l], aF[l], aQ[l], 100 * (aQ[l] / aF[l] - 1));
+}
+
+// ---------------------------------------------------------------- the one-request form (bvh_build.h Slot16)
+void packQ8(Built& b, uint32_t shift) {
+  if (const char* e = getenv("RT_Q8_SHIFT")) shift = (uint32_t)atoi(e);  // (experiments: slots per block = 1 << shift)
+  b.q8.clear(), b.q8Shift = shift, b.q8Blocks = 0;
+  if (b.leafMax > 2) throw std::runtime_error("the Q8 node format holds leaves of at most 2 triangles");
+  if (shift < 4 || shift > 16) throw std::runtime_error("Q8 block shift out of range");
+  const uint32_t n = static_cast<uint32_t>(b.nodes.size());
+  if (n == 0) return;
+  const uint32_t B = 1u << shift;
+  // Blocks are TREELETS, because a block's frame is the union of the boxes its records hold and the grid step is 1 / 255
+  // of it: (a) the top of a subtree too big for one block, grown from its root by box area until the block is full —
+  // the frame is the root's box and the members are its upper levels; (b) whole subtrees that fit, several neighbouring
+  // ones per block as long as they hang below one ancestor of at most two blocks' worth (so the union stays a compact
+  // region).  Depth-first order over the whole tree (measured first) put the record of every right sibling the walk
+  // returned to, levels above, among leaf-level records, and two thirds of the blocks got grids 2-16 x too coarse.
+  std::vector<uint32_t> slotOf(n, ~0u), groupOf(n, ~0u), need(n, 0), tin(n, 0), tout(n, 0);
+  std::vector<int32_t> parent(n, -1);
+  auto itemSlots = [](int32_t ref) { return ref >= 0 ? 1u : 3u * ((~(uint32_t)ref & 7u) + 1u); };
+  auto groupSlots = [&](int32_t i) { return itemSlots(b.nodes[i].child[0]) + itemSlots(b.nodes[i].child[1]); };
+  {
+    // pre-order numbers, parents, and the slots the groups of a whole subtree need (children before parents)
+    std::vector<std::pair<int32_t, int>> st{{0, 0}};
+    uint32_t clock = 0;
+    while (!st.empty()) {
+      auto& [i, phase] = st.back();
+      if (phase == 0) tin[i] = clock++;
+      if (phase < 2) {
+        const int32_t c = b.nodes[i].child[phase++];
+        if (c >= 0) parent[c] = i, st.push_back({c, 0});
+      } else {
+        uint64_t m = groupSlots(i);
+        for (int k = 0; k < 2; ++k)
+          if (b.nodes[i].child[k] >= 0) m += need[b.nodes[i].child[k]];
+        need[i] = (uint32_t)std::min<uint64_t>(m, 0xffffffffu);
+        tout[i] = clock;
+        st.pop_back();
+      }
+    }
+  }
+  auto area = [](const float* lo, const float* hi) {
+    const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  struct Item {
+    double a;
+    int32_t idx;
+    bool operator<(const Item& o) const { return a < o.a || (a == o.a && idx > o.idx); }  // max-heap, low index first
+  };
+  struct Layout {
+    const Built& b;
+    uint32_t B;
+    std::vector<uint32_t>&slotOf, &groupOf, &need, &tin, &tout;
+    std::vector<int32_t>& parent;
+    uint64_t pos = 0, blockEnd = 0;
+    int32_t firstRoot = -1;  // the first whole subtree placed in the open block; -1: the block takes no (more) subtrees
+    bool fresh = false;
+    void openBlock() {
+      pos = (pos + B - 1) & ~(uint64_t)(B - 1);
+      blockEnd = pos + B;
+      pos += 1;  // slot 0: the frame
+      firstRoot = -1, fresh = true;
+      if (blockEnd >= (1ull << 27)) throw std::runtime_error("the tree exceeds the 2 GiB the Q8 node format addresses");
+    }
+    uint32_t freeSlots() const { return (uint32_t)(blockEnd - pos); }
+    static uint32_t itemSlots(int32_t ref) { return ref >= 0 ? 1u : 3u * ((~(uint32_t)ref & 7u) + 1u); }
+    void placeGroup(int32_t i) {
+      const Node& nd = b.nodes[i];
+      const uint32_t s0 = itemSlots(nd.child[0]), s1 = itemSlots(nd.child[1]);
+      const uint32_t g = (uint32_t)pos;
+      pos += s0 + s1;
+      groupOf[i] = g;
+      if (nd.child[0] >= 0) slotOf[nd.child[0]] = g;
+      if (nd.child[1] >= 0) slotOf[nd.child[1]] = g + s0;
+    }
+    void placeSubtree(int32_t f) {  // depth-first over sibling pairs
+      std::vector<int32_t> st{f};
+      while (!st.empty()) {
+        const int32_t x = st.back();
+        st.pop_back();
+        placeGroup(x);
+        if (b.nodes[x].child[1] >= 0) st.push_back(b.nodes[x].child[1]);
+        if (b.nodes[x].child[0] >= 0) st.push_back(b.nodes[x].child[0]);
+      }
+    }
+    bool compatible(int32_t f) const {
+      if (fresh) return true;
+      if (firstRoot < 0) return false;
+      int32_t a = f;
+      while (!(tin[a] <= tin[firstRoot] && tin[firstRoot] < tout[a])) a = parent[a];
+      return need[a] <= 2u * (B - 1u);
+    }
+    // the upper levels of subtree f into the open block, by box area; what does not fit is returned (pre-order)
+    std::vector<int32_t> growTop(int32_t f, const std::function<double(const float*, const float*)>& area) {
+      std::vector<Item> heap{{1e300, f}};
+      std::vector<int32_t> frontier;
+      while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end());
+        const Item it = heap.back();
+        heap.pop_back();
+        const Node& nd = b.nodes[it.idx];
+        if (itemSlots(nd.child[0]) + itemSlots(nd.child[1]) > freeSlots()) {
+          frontier.push_back(it.idx);
+          continue;
+        }
+        placeGroup(it.idx);
+        if (nd.child[0] >= 0) heap.push_back({area(nd.lo0, nd.hi0), nd.child[0]}), std::push_heap(heap.begin(), heap.end());
+        if (nd.child[1] >= 0) heap.push_back({area(nd.lo1, nd.hi1), nd.child[1]}), std::push_heap(heap.begin(), heap.end());
+      }
+      fresh = false, firstRoot = -1;
+      std::sort(frontier.begin(), frontier.end(), [&](int32_t x, int32_t y) { return tin[x] < tin[y]; });
+      return frontier;
+    }
+    void layoutList(const std::vector<int32_t>& roots, const std::function<double(const float*, const float*)>& area) {
+      for (const int32_t f : roots) {
+        if (need[f] <= freeSlots() && compatible(f)) {
+          if (fresh) firstRoot = f, fresh = false;
+          placeSubtree(f);
+        } else if (need[f] <= B - 1u) {
+          openBlock();
+          firstRoot = f, fresh = false;
+          placeSubtree(f);
+        } else {
+          openBlock();
+          const std::vector<int32_t> frontier = growTop(f, area);
+          layoutList(frontier, area);
+        }
+      }
+    }
+  } L{b, B, slotOf, groupOf, need, tin, tout, parent};
+  L.openBlock();
+  slotOf[0] = (uint32_t)L.pos++;
+  if (slotOf[0] * 16u != kQ8RootOffset) throw std::runtime_error("internal error: Q8 root slot");
+  if (need[0] <= L.freeSlots()) {
+    L.placeSubtree(0);
+  } else {
+    const std::vector<int32_t> frontier = L.growTop(0, area);
+    L.layoutList(frontier, area);
+  }
+  const uint64_t pos = L.pos;
+  for (uint32_t i = 0; i < n; ++i)
+    if (slotOf[i] == ~0u || groupOf[i] == ~0u) throw std::runtime_error("internal error: Q8 layout lost a node");
+  const uint32_t nSlots = static_cast<uint32_t>(pos), nBlocks = (nSlots + B - 1) >> shift;
+  b.q8.assign(nSlots, Slot16{{0, 0, 0, 0}});
+  b.q8Blocks = nBlocks;
+  // frames: the union of the child boxes stored in each block's records; one step for the three axes
+  std::vector<Box> fb(nBlocks);
+  for (Box& x : fb) x.reset();
+  for (uint32_t i = 0; i < n; ++i) {
+    Box& x = fb[slotOf[i] >> shift];
+    x.grow(b.nodes[i].lo0), x.grow(b.nodes[i].hi0), x.grow(b.nodes[i].lo1), x.grow(b.nodes[i].hi1);
+  }
+  std::vector<double> step(nBlocks, 0.0);
+  for (uint32_t k = 0; k < nBlocks; ++k) {
+    const Box& x = fb[k];
+    if (!(x.lo[0] <= x.hi[0])) continue;  // a block of triangle records only
+    double ext = 0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, (double)x.hi[a] - (double)x.lo[a]);
+    // the step: any float will do (a plane = origin + q * step is exact in double either way), a power of two would
+    // waste up to half of the 256 levels
+    float sf0 = (float)(std::max(ext, 1e-30) / 255.0);
+    if ((double)sf0 * 255.0 < ext) sf0 = std::nextafter(sf0, std::numeric_limits<float>::infinity());
+    double s = std::max((double)sf0, 1e-30);
+    for (int a = 0; a < 3; ++a)
+      while (std::ceil(((double)x.hi[a] - (double)x.lo[a]) / s) > 255.0) s = (double)std::nextafter((float)s, std::numeric_limits<float>::infinity());
+    step[k] = s;
+    Slot16& h = b.q8[(size_t)k << shift];
+    const float sf = (float)s;
+    std::memcpy(&h.w[0], &x.lo[0], 4), std::memcpy(&h.w[1], &x.lo[1], 4), std::memcpy(&h.w[2], &x.lo[2], 4), std::memcpy(&h.w[3], &sf, 4);
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    const Node& nd = b.nodes[i];
+    const uint32_t k = slotOf[i] >> shift;
+    const double s = step[k];
+    const float* o = fb[k].lo;
+    uint8_t q[12];
+    for (int c = 0; c < 2; ++c)
+      for (int a = 0; a < 3; ++a) {
+        const double lo = c ? nd.lo1[a] : nd.lo0[a], hi = c ? nd.hi1[a] : nd.hi0[a];
+        double ql = std::floor((lo - (double)o[a]) / s), qh = std::ceil((hi - (double)o[a]) / s);
+        ql = std::max(ql, 0.0);
+        while (ql > 0.0 && (double)o[a] + ql * s > lo) ql -= 1.0;
+        while ((double)o[a] + qh * s < hi) qh += 1.0;
+        if (!((double)o[a] + ql * s <= lo) || qh > 255.0 || ql > qh) throw std::runtime_error("internal error: Q8 plane outside its frame");
+        q[6 * c + 2 * a] = (uint8_t)ql, q[6 * c + 2 * a + 1] = (uint8_t)qh;
+      }
+    Slot16& r = b.q8[slotOf[i]];
+    std::memcpy(r.w, q, 12);
+    uint32_t flags = 0;
+    for (int c = 0; c < 2; ++c)
+      if (nd.child[c] < 0) flags |= (1u << c) | ((((~(uint32_t)nd.child[c]) & 7u) ? 4u : 0u) << c);
+    r.w[3] = (groupOf[i] << 4) | flags;
+    uint32_t at = groupOf[i];
+    for (int c = 0; c < 2; ++c) {
+      if (nd.child[c] >= 0) {
+        if (slotOf[nd.child[c]] != at) throw std::runtime_error("internal error: Q8 sibling items not adjacent");
+        at += 1;
+      } else {
+        const uint32_t code = ~(uint32_t)nd.child[c], first = code >> 3, cnt = (code & 7u) + 1u;
+        for (uint32_t t = 0; t < cnt; ++t) std::memcpy(&b.q8[at + 3u * t], &b.tris[first + t], sizeof(TriRec));
+        at += 3u * cnt;
+      }
+    }
+  }
+  if (getenv("RT_BVH_VERBOSE")) {
+    reportQ8(b);
+    std::vector<uint32_t> hist(64, 0);
+    for (uint32_t k = 0; k < nBlocks; ++k)
+      if (step[k] > 0) {
+        int e = 0;
+        std::frexp(step[k], &e);
+        hist[std::min(63, std::max(0, e + 40))]++;
+      }
+    for (int e = 0; e < 64; ++e)
+      if (hist[e]) fprintf(stderr, "Q8 blocks with step 2^%d: %u\n", e - 41, hist[e]);
+  }
+}
+
+void decodeQ8(const Built& b, uint32_t byteOffset, float lo[2][3], float hi[2][3], int32_t child[2]) {
+  const uint32_t slot = byteOffset >> 4;
+  if ((byteOffset & 15u) || slot >= b.q8.size() || (slot & ((1u << b.q8Shift) - 1u)) == 0) throw std::runtime_error("Q8 record offset out of range");
+  const Slot16& h = b.q8[(size_t)(slot >> b.q8Shift) << b.q8Shift];
+  const Slot16& r = b.q8[slot];
+  float o[3], s;
+  std::memcpy(o, h.w, 12), std::memcpy(&s, &h.w[3], 4);
+  uint8_t q[12];
+  std::memcpy(q, r.w, 12);
+  for (int c = 0; c < 2; ++c)
+    for (int a = 0; a < 3; ++a) {
+      // (exact in double: a float plus at most 255 steps of a power of two)
+      const double dl = (double)o[a] + (double)q[6 * c + 2 * a] * (double)s, dh = (double)o[a] + (double)q[6 * c + 2 * a + 1] * (double)s;
+      float fl = (float)dl, fh = (float)dh;
+      if ((double)fl < dl) fl = std::nextafter(fl, std::numeric_limits<float>::infinity());   // report the box no LARGER than it is:
+      if ((double)fh > dh) fh = std::nextafter(fh, -std::numeric_limits<float>::infinity());  // the check must hold for the exact planes
+      lo[c][a] = fl, hi[c][a] = fh;
+    }
+  const uint32_t ref = r.w[3], base = ref & ~15u;
+  const bool leaf0 = ref & 1u, leaf1 = ref & 2u;
+  const uint32_t cnt0 = (ref >> 2) & 1u, cnt1 = (ref >> 3) & 1u;
+  const uint32_t off1 = base + (leaf0 ? 48u * (cnt0 + 1u) : 16u);
+  child[0] = leaf0 ? (int32_t)~(base | cnt0) : (int32_t)base;
+  child[1] = leaf1 ? (int32_t)~(off1 | cnt1) : (int32_t)off1;
+}
+
 void relayoutAndPack(Built& b) {
   relayoutTop(b.nodes, kTopNodes);
   packNodes(b);
@@ -1147,25 +1245,6 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   }
   out.nodes.swap(top.nodes);
   out.maxDepth = top.maxDepth;
-  {
-    // reinsertion passes (RT_BVH_REINSERT overrides; 0 = off)
-    const char* e = getenv("RT_BVH_REINSERT");
-    const int passes = e ? atoi(e) : 0;
-    if (passes > 0 && out.nodes.size() > 2) {
-      Reinserter R;
-      R.depthCap = B.depthCap;
-      R.load(out.nodes);
-      const double a0 = R.innerArea();
-      for (int p = 0; p < passes; ++p) {
-        const uint64_t before = R.moves;
-        R.pass(0.f);
-        if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "reinsertion pass %d: %llu moves, inner area %.6g -> %.6g\n", p, (unsigned long long)(R.moves - before), a0, R.innerArea());
-        if (R.moves == before) break;
-      }
-      R.store(out.nodes);
-      out.maxDepth = R.it[0].height;
-    }
-  }
   {
     // rotation passes (RT_BVH_ROT overrides; 0 = off).  Measured with 4: nodes/ray 9.06 -> 8.71
     // on C2 (+1.9 %), 38.1 -> 37.2 on C5 (+1.1 %); SAH cost -3 % / -0.3 % / -2.4 % (1.2 k /

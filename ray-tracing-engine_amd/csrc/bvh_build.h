@@ -51,20 +51,26 @@ struct alignas(16) Node16 {  // 32 B
 };
 static_assert(sizeof(Node16) == 32, "packed node record must be 32 bytes");
 
-// The WIDE form (round 3): up to four children per record — the binary SAH tree collapsed (an inner
-// child is replaced by its own two children, largest box first) — so that a ray makes about half as
-// many DEPENDENT node fetches: on scenes that do not fit the caches a wave's traversal step costs
-// the miss latency of its slowest lane whatever the record holds, and halving the steps is what
-// shortens the frame.  Same plane encoding as Node16 (binary16 of coordinate * boxScale, rounded
-// outward, (lo, hi) pairs per axis), same child refs; one 64-byte record = half a cache line, never
-// straddling one.  Unused slots hold an inverted box (lo = +65504, hi = -65504: no finite ray
-// enters it) and a copy of slot 0's ref, so that even a degenerate ray that "hits" one walks a
-// valid subtree twice instead of a wild pointer.
-struct alignas(64) Node4x16 {  // 64 B
-  uint16_t box[4][6];          // box[c][2 * axis] = lo, box[c][2 * axis + 1] = hi
-  int32_t child[4];            // >= 0: BYTE offset of the child's record (index * 64); < 0: leaf, as Node16
+// The ONE-REQUEST form (round 4): a 16-byte record, so that a node visit costs the CU's vector L1 one divergent
+// request instead of two — on trees the caches do not hold, the traversal sits on that unit's request rate
+// (DESIGN.md §4.3).  Nodes AND triangle records live in one array of 16-byte slots, cut into blocks of
+// 2^blockShift slots (16 KiB by default); slot 0 of every block is its FRAME {origin x, y, z, step} and the 12
+// box planes of a record are 8-bit grid coordinates in the frame of the record's own block: plane = origin +
+// q * step, step a power of two, lower planes rounded down and upper planes up (the decoded box contains the
+// padded float box: the exactness argument of the binary16 form carries over).  Byte order: child 0 x lo, x hi,
+// y lo, y hi | child 0 z lo, z hi, child 1 x lo, x hi | child 1 y lo, y hi, z lo, z hi — each word holds two
+// (lo, hi) pairs, ordered along the ray by one v_perm_b32 per word.  The two children's ITEMS (an inner child:
+// its 16-byte record; a leaf: its 1 or 2 triangle records, 48 bytes each) are adjacent, child 0 first, so ONE
+// word locates both: ref = byte offset of child 0's item | bit 0: child 0 is a leaf, bit 1: child 1 is a leaf,
+// bit 2 / bit 3: that leaf holds 2 triangles.  Layout: the most-visited top first (greedily by box area from
+// the root, as relayoutTop does), then the subtrees depth-first over sibling pairs, so a block is a compact
+// piece of the tree (fine grid) and a leaf's triangles sit a few slots from the record that refers to them.
+struct alignas(16) Slot16 {
+  uint32_t w[4];
 };
-static_assert(sizeof(Node4x16) == 64, "wide node record must be 64 bytes");
+static_assert(sizeof(Slot16) == 16, "slot must be 16 bytes");
+constexpr uint32_t kQ8BlockShift = 10;  // 1,024 slots = 16 KiB per block
+constexpr uint32_t kQ8RootOffset = 16;  // the root's record: slot 1 (slot 0 is block 0's frame)
 
 struct alignas(16) TriRec { // 48 B
   float p0[3], e1[3], e2[3];
@@ -78,13 +84,10 @@ constexpr int kMaxDepth = 32;      // traversal stack entries per lane
 // LDS budget of the pooled render kernel (rt_kernels.hip plan_persist), which the depth cap is chosen
 // against: words per CU available to the waves, words of a wave's ray pool, words per stack row
 // (the diagnostic RT_PHASE_TIMING build keeps 256 B of static LDS; the product build has none)
-// (kCtlWords: the persistent workgroup's control block — pool descriptors and the availability mask of
-// the CU-level ray sharing, rt_kernels.hip vertex_pool_cus — sits behind the waves' regions)
-constexpr uint32_t kCtlWords = 80u;
 #ifdef RT_PHASE_TIMING
-constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - 64u - kCtlWords;
+constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - 64u;
 #else
-constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u - kCtlWords;
+constexpr uint32_t kLdsWordsPerCU = 160u * 1024u / 4u;
 #endif
 constexpr uint32_t kWavePoolWords = 1128u, kStackRowWords = 64u;
 // waves (of at most 16) that fit a CU beside their stacks for a tree of this depth (+1: the sentinel row)
@@ -123,16 +126,10 @@ struct Built {
   int depthCap = kMaxDepth - 1;  // the cap the tree was built under
   float pad = 0.f;
   float originBound = 0.f;      // ray origins with a larger |coordinate| are outside the padding analysis
-  // wide form of the same tree (collapse4): empty unless requested
-  std::vector<Node4x16> nodes4;
-  uint32_t stackNeed4 = 0;      // most entries a lane's traversal stack can hold on this wide tree
-  double visitCost2 = 0, visitCost4 = 0;  // SAH estimate of node visits per random ray, binary / wide
+  // the one-request form (packQ8): empty unless requested
+  std::vector<Slot16> q8;
+  uint32_t q8Shift = 0, q8Blocks = 0;
 };
-// Collapses b.nodes (binary, float boxes) into b.nodes4.  `stackBudget` bounds the stack entries any
-// root-to-leaf path can pile up (a 4-wide node pushes up to three): merges that would exceed it on a
-// deep path are not made, so the LDS stack of the render kernel stays as small as the binary tree's.
-// 0 = the binary tree's own need (its depth).
-void collapse4(Built& b, uint32_t stackBudget = 0);
 
 // What both builders (host: build(); device: csrc/bvh_gpu.hip) derive from the scene
 // before touching a triangle: validation (throws std::runtime_error on an inconsistent
@@ -151,6 +148,13 @@ float halfToFloat(uint16_t h);
 // depend on it.
 void build(const rt_scene_desc& scene, uint32_t leafMax, Built& out, uint32_t threads = 0);
 void packNodes(Built& b);  // b.nodes (float boxes) -> b.nodes16 (the device records)
+// b.nodes + b.tris -> b.q8 (the unified array of the one-request form).  Throws when the tree cannot be expressed
+// (leaves of more than 2 triangles, more than 2 GiB of slots).
+void packQ8(Built& b, uint32_t blockShift = kQ8BlockShift);
+// One record of b.q8 decoded as the kernels decode it: the two child boxes (float arithmetic of the exact grid
+// values) and the child refs in the traversal's form (>= 0: byte offset of the child's record; < 0: leaf,
+// ~(byte offset of its first triangle record | count - 1)).
+void decodeQ8(const Built& b, uint32_t byteOffset, float lo[2][3], float hi[2][3], int32_t child[2]);
 // Final numbering of b.nodes (most-visited top first, see bvh_build.cpp relayoutTop) + packNodes.
 void relayoutAndPack(Built& b);
 // Measured-cost tuning (bvh_build.cpp): `measure` returns the cost of the tree now in b.nodes (it packs and uploads

@@ -97,7 +97,6 @@ struct rt_ctx {
   TileKey tileKey;
   unsigned long long* dCounters = nullptr;
   uint32_t* dTileCounter = nullptr;  // work queue head of the persistent render kernel
-  uint32_t* dSsOver = nullptr;       // short-stack overflow columns (deep trees only)
   // owned-granule lists of the ranks of a tile-sharded frame (multi-GPU assembly), by key
   struct GranList {
     uint32_t* d = nullptr;
@@ -112,6 +111,7 @@ struct rt_ctx {
   size_t wfCap = 0;
   void* wfBlock = nullptr;
   uint32_t builder = RT_BVH_HOST;
+  uint32_t nodeFormat = RT_NODES_F16;  // what the pooled render kernel and rt_trace traverse
   float buildMs = 0.f;
   uint32_t numCUs = 0;
   hipEvent_t ev[kEventPairs][2];
@@ -273,6 +273,7 @@ int read_counters(rt_ctx* c, rt_stats* st) {
   st->nodes_visited = h[RTK_CNT_NODES];
   st->tris_tested = h[RTK_CNT_TRIS];
   st->kd_visited = h[RTK_CNT_KD];
+  st->frame_fetches = h[RTK_CNT_FRAMES];
   st->reserved[0] = h[RTK_CNT_WNODE];  // diagnostics (collect_stats): wave-level node steps,
   st->reserved[1] = h[RTK_CNT_WLEAF];  // wave-level leaf phases -> lane utilisation of the traversal
   st->reserved[2] = h[RTK_CNT_LWAIT];  // lanes holding a leaf / lanes without a ray at the START of the round,
@@ -315,22 +316,11 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   }
   // (+1: row 0 of a lane's stack is the TERM sentinel, rt_kernels.hip Trav)
   A.stackLevels = (levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels) + 1u;
-  // the wide tree: its own stack need + the sentinel row + the two rows a step writes ahead of the top
-  A.stackLevelsWide = (c->bvh.stackNeed4 > 1 ? c->bvh.stackNeed4 : 1u) + 3u;
   A.tileCounter = c->dTileCounter, A.numCUs = c->numCUs, A.waveWords = 0, A.tilesPerBlock = 1;
-  A.ssOver = c->dSsOver;
   const int e = c->evUsed % kEventPairs;
   // rt_params.reserved[2] bit 0: the queue-based (wavefront) integrator — BVH direct lighting with
   // at most 3 lights, like the pooled kernel; same frame bit for bit
-  // RT_PHOTON_STREAM=1 (opt-in): photon-map shading in ray mode (BASELINE config 3) as a QUERY STREAM
-  // (wavefront_kernels.h k_knn_stream: lanes that finish their k-NN walk take the next query instead of waiting for the
-  // slowest of 64).  Same frame bit for bit — and 2 x SLOWER (28.5 against 14.3 ms: DESIGN.md section 4.6): lanes that
-  // start their walks at different times are in different branches of the walk at every step, and a wave pays for
-  // every branch any of its lanes is in (VALU lane utilisation 0.29 against 0.58).  Not with counters (the fused kernel
-  // owns the node / kd-visit counters).
-  static const bool photonStreamOn = getenv("RT_PHOTON_STREAM") && atoi(getenv("RT_PHOTON_STREAM")) != 0;
-  const bool photonStream = photonStreamOn && p->use_photons && p->mode == RT_MODE_RAY && p->accel != RT_ACCEL_BRUTE && !p->collect_stats;
-  if (photonStream || ((p->reserved[2] & 1u) && !p->use_photons && p->accel != RT_ACCEL_BRUTE && c->S.n_lights <= 3u)) {
+  if ((p->reserved[2] & 1u) && !p->use_photons && p->accel != RT_ACCEL_BRUTE && c->S.n_lights <= 3u) {
     rt_ctx::GranList G;
     rc = ensure_granules(c, p, p->rank, &G);
     if (rc != RT_OK) return rc;
@@ -348,8 +338,8 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
     if (P > c->wfCap) {
       if (c->wfBlock) HIP_TRY(hipFree(c->wfBlock));
       c->wfBlock = nullptr, c->wfCap = 0;
-      // rng 4, org 16, dir 16, key 8, nrm 16, pnt 16, knn 16, col 48, rayO 64, rayD 64, res 32 = 300 B per path
-      const size_t bytes = P * 300 + 4096 + 2048 * sizeof(unsigned long long);
+      // rng 4, org 16, dir 16, key 8, nrm 16, pnt 16, col 48, rayO 64, rayD 64, res 32 = 284 B per path
+      const size_t bytes = P * 284 + 4096 + 2048 * sizeof(unsigned long long);
       HIP_TRY(hipMalloc(&c->wfBlock, bytes));
       char* q = static_cast<char*>(c->wfBlock);
       auto take = [&](size_t n) {
@@ -362,7 +352,6 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
       W.col = reinterpret_cast<float4*>(take(P * 48));
       W.org = reinterpret_cast<float4*>(take(P * 16)), W.dir = reinterpret_cast<float4*>(take(P * 16));
       W.nrm = reinterpret_cast<float4*>(take(P * 16)), W.pnt = reinterpret_cast<float4*>(take(P * 16));
-      W.knn = reinterpret_cast<float4*>(take(P * 16));
       W.res = reinterpret_cast<uint2*>(take(P * 32)), W.key = reinterpret_cast<uint2*>(take(P * 8));
       W.rng = reinterpret_cast<uint32_t*>(take(P * 4));
       W.stripes = reinterpret_cast<unsigned long long*>(take(2048 * sizeof(unsigned long long)));
@@ -373,10 +362,7 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
     W.gran = G.d, W.nGran = G.n, W.width = p->width, W.height = p->height, W.spp = p->spp, W.seed = p->seed;
     W.s0 = A.s0, W.s1 = A.s1, W.batch = (uint32_t)batch, W.nPaths = 0;
     HIP_TRY(hipEventRecord(c->ev[e][0], stream));
-    hipError_t hw = photonStream ? rtk::launch_wavefront_photon(c->S, W, p->k, p->photons_requested, dAccum, c->dCounters, c->dTileCounter,
-                                                                c->numCUs, stream)
-                                 : rtk::launch_wavefront(c->S, W, p->mode, p->max_depth, dAccum, c->dCounters, c->dTileCounter, A.stackLevels,
-                                                         c->numCUs, stream);
+    hipError_t hw = rtk::launch_wavefront(c->S, W, p->mode, p->max_depth, dAccum, c->dCounters, c->dTileCounter, A.stackLevels, c->numCUs, stream);
     if (hw != hipSuccess) return fail(RT_ERR_HIP, "wavefront launch failed: %s", hipGetErrorString(hw));
     HIP_TRY(hipEventRecord(c->ev[e][1], stream));
     c->evUsed++;
@@ -432,10 +418,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   c->device = opt ? opt->device : 0;
   // the tree: host SAH builder, or the device builder (tiny scenes always take the host's
   // special cases)
-  // (the 4-wide form is collapsed from the host builder's float nodes: asking for it selects the host builder)
-  const char* wideEnv = getenv("RT_BVH_WIDE");
-  const bool wideWanted = wideEnv ? atoi(wideEnv) != 0 : (opt && opt->bvh_width == 4);
-  const bool gpuBuild = ((opt && opt->bvh_builder == RT_BVH_DEVICE) || getenv("RT_BVH_GPU")) && sc->n_triangles >= 16 && !wideWanted;
+  const bool gpuBuild = ((opt && opt->bvh_builder == RT_BVH_DEVICE) || getenv("RT_BVH_GPU")) && sc->n_triangles >= 16;
   rtbvh::ScenePlan plan;
   const auto tBuild0 = std::chrono::steady_clock::now();
   try {
@@ -446,14 +429,6 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
       c->bvh = *prebuilt;
     } else {
       rtbvh::build(*sc, opt ? opt->bvh_leaf_max : 0, c->bvh);
-    }
-    // the wide (4-ary) form: OPT-IN (rt_options.bvh_width = 4 or RT_BVH_WIDE=1; host-built trees only).
-    // Measured on MI355X: 0.71x the node visits but 4 instead of 2 vector-memory
-    // requests per visit, and the CU's vector L1 — which serves ~0.7-0.9 divergent 16-B requests per
-    // clock whatever their hit level — is what binds the big scenes: 1 M triangles 407 vs 357 ms.
-    if (!gpuBuild && wideWanted && c->bvh.nodes4.empty()) {
-      const char* wb = getenv("RT_BVH_WIDE_BUDGET");
-      rtbvh::collapse4(c->bvh, wb ? (uint32_t)atoi(wb) : 0u);
     }
   } catch (const std::exception& e) {
     delete c;
@@ -490,12 +465,46 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     c->builder = RT_BVH_DEVICE;
   } else {
     UP(nodes, c->bvh.nodes16.data(), c->bvh.nodes16.size() * 2);
-    static_assert(sizeof(rtbvh::Node4x16) == 4 * sizeof(uint4), "wide node layout");
-    UP(nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4);
-    S.n_nodes4 = static_cast<uint32_t>(c->bvh.nodes4.size());
     UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);
     UP(trisRef, c->bvh.trisRef.data(), c->bvh.trisRef.size() * 3);
     S.n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
+  }
+  // The node records the pooled render kernel and rt_trace traverse (rt_options.node_format; RT_NODES=f16|q8 overrides).
+  // RT_NODES_Q8 — 16-byte records, ONE vector-memory request per visit (bvh_build.h Slot16) — is for trees the caches do
+  // not hold, where the traversal sits on the vector L1's request rate.  The other kernels (photon emission, ray streams,
+  // the wavefront integrator, the one-wave-per-workgroup render instances) keep the 32-byte records, so both forms are resident.
+  {
+    uint32_t want = opt ? opt->node_format : (uint32_t)RT_NODES_AUTO;
+    if (const char* e = getenv("RT_NODES")) want = !strcmp(e, "q8") ? (uint32_t)RT_NODES_Q8 : !strcmp(e, "f16") ? (uint32_t)RT_NODES_F16 : want;
+    if (want > RT_NODES_Q8) {
+      rt_destroy(c);
+      return fail(RT_ERR_INVALID, "unknown node_format %u", want);
+    }
+    if (want == RT_NODES_AUTO) want = RT_NODES_F16;
+    if (want == RT_NODES_Q8) {
+      try {
+        if (gpuBuild) {  // the packer works from the float records: fetch what the device builder left on the device
+          c->bvh.nodes.resize(S.n_nodes), c->bvh.tris.resize(sc->n_triangles), c->bvh.trisRef.resize(sc->n_triangles);
+          if (hipMemcpy(c->bvh.nodes.data(), c->dNodesF, (size_t)S.n_nodes * sizeof(rtbvh::Node), hipMemcpyDeviceToHost) != hipSuccess ||
+              hipMemcpy(c->bvh.tris.data(), S.tris, (size_t)sc->n_triangles * sizeof(rtbvh::TriRec), hipMemcpyDeviceToHost) != hipSuccess ||
+              hipMemcpy(c->bvh.trisRef.data(), S.trisRef, (size_t)sc->n_triangles * sizeof(rtbvh::TriRec), hipMemcpyDeviceToHost) != hipSuccess)
+            throw std::runtime_error("reading the device-built tree back failed");
+        }
+        if (c->bvh.q8.empty()) rtbvh::packQ8(c->bvh);
+        if (gpuBuild) c->bvh.nodes.clear(), c->bvh.tris.clear(), c->bvh.trisRef.clear();  // (rt_bvh_export reads the device copies)
+      } catch (const std::exception& e) {
+        rt_destroy(c);
+        return fail(RT_ERR_UNSUPPORTED, "node_format RT_NODES_Q8: %s", e.what());
+      }
+      static_assert(sizeof(rtbvh::Slot16) == sizeof(uint4), "slot layout");
+      if ((rc = upload_owned(c, &S.q8, c->bvh.q8.data(), c->bvh.q8.size())) != RT_OK) {
+        rt_destroy(c);
+        return rc;
+      }
+      S.q8ShiftBytes = c->bvh.q8Shift + 4u;
+      c->nodeFormat = RT_NODES_Q8;
+      std::vector<rtbvh::Slot16>().swap(c->bvh.q8);  // (the host copy is not needed again)
+    }
   }
   c->buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count();
   UP(mats, sc->materials, sc->n_meshes);
@@ -579,7 +588,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   S.stealT = getenv("RT_STEALT") ? atoi(getenv("RT_STEALT")) : 8;
   S.refillT = getenv("RT_REFILLT") ? atoi(getenv("RT_REFILLT")) : bigTree ? 32 : 24;
   S.phPos = S.phDir = nullptr;
-  S.topK = 0, S.ssRows = 0, S.ssOvRows = 0, S.ssOver = nullptr;
+  S.topK = 0;
   S.cam = sc->camera;
   {
     int cus = 0;
@@ -588,18 +597,9 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
       rt_destroy(c);
       return fail(RT_ERR_HIP, "tile counter allocation failed");
     }
-    // trees deeper than the short stack's 12 LDS entries: overflow columns in HBM, one per lane of
-    // every wave the persistent kernel can have in flight (numCUs x 16 waves x 32 rows x 256 B)
-    // (the short stack is opt-in, RT_SS=1: without it no launch plan selects LT_SS and the 32 MiB stay unallocated)
-    const char* ssEnv = getenv("RT_SS");
     if (c->numCUs == 0) {
       rt_destroy(c);
       return fail(RT_ERR_HIP, "device %d reports no compute units", c->device);
-    }
-    if (ssEnv && atoi(ssEnv) != 0 && c->bvh.maxDepth > 1 &&
-        hipMalloc(reinterpret_cast<void**>(&c->dSsOver), (size_t)c->numCUs * 16u * 32u * 64u * sizeof(uint32_t)) != hipSuccess) {
-      rt_destroy(c);
-      return fail(RT_ERR_HIP, "short-stack overflow allocation failed");
     }
   }
   // (the counter block + 1,024 striped slots x 4 for the one-wave-per-workgroup kernels: rt_kernels.hip flush_stats_striped)
@@ -630,7 +630,6 @@ void rt_destroy(rt_ctx* c) {
   if (c->dTiles) (void)hipFree(c->dTiles);
   if (c->dCounters) (void)hipFree(c->dCounters);
   if (c->dTileCounter) (void)hipFree(c->dTileCounter);
-  if (c->dSsOver) (void)hipFree(c->dSsOver);
   if (c->dNodesF) (void)hipFree(c->dNodesF);
   if (c->wfBlock) (void)hipFree(c->wfBlock);
   for (auto& kv : c->granules)
@@ -877,7 +876,7 @@ int rt_bvh_info_get(rt_ctx* c, rt_bvh_info* out) {
   out->pad = c->bvh.pad;
   out->build_ms = c->buildMs;
   out->builder = c->builder;
-  out->n_wide_nodes = c->S.n_nodes4;
+  out->node_format = c->nodeFormat;
   return RT_OK;
 }
 
@@ -919,83 +918,120 @@ int rt_bvh_build_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t threa
   return RT_OK;
 }
 
-int rt_bvh_wide_check_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t stack_budget, uint32_t* out8, double* est2) {
+int rt_bvh_check_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t node_format, uint32_t* out8, double* est2) {
   if (!sc || !out8) return fail(RT_ERR_INVALID, "null argument");
+  if (node_format != RT_NODES_F16 && node_format != RT_NODES_Q8) return fail(RT_ERR_INVALID, "node_format must be RT_NODES_F16 or RT_NODES_Q8");
   try {
     rtbvh::Built b;
     rtbvh::build(*sc, leaf_max, b, 0);
-    rtbvh::collapse4(b, stack_budget);
-    const size_t nw = b.nodes4.size();
-    if (nw == 0) return fail(RT_ERR_STATE, "collapse produced no nodes");
+    const bool q8 = node_format == RT_NODES_Q8;
+    if (q8) rtbvh::packQ8(b);
+    const size_t nn = b.nodes16.size();
+    if (nn == 0 || nn != b.nodes.size()) return fail(RT_ERR_STATE, "the build produced no packed nodes");
     const float inv = 1.f / b.boxScale;
     std::vector<uint32_t> seen(b.tris.size(), 0);
-    uint32_t kcount[5] = {0, 0, 0, 0, 0};
-    uint32_t maxStack = 0;
-    std::vector<uint8_t> visited(nw, 0);
-    // depth-first over the wide tree; returns the float box of everything below a child ref
+    std::vector<uint8_t> visited(q8 ? b.q8.size() : nn, 0);
+    uint32_t depthSeen = 0;
+    double areaSum = 0;  // inner children's decoded box areas (the visit estimate of the packed form)
+    // depth-first over the packed tree; returns the float box of the geometry below a child ref
     struct Bx { float lo[3], hi[3]; };
     struct Walker {
       const rt_scene_desc& sc; const rtbvh::Built& b; std::vector<uint32_t>& seen; std::vector<uint8_t>& visited;
-      uint32_t* kcount; uint32_t& maxStack; float inv; std::string err;
-      Bx walk(int32_t ref, uint32_t used) {
+      uint32_t& depthSeen; double& areaSum; float inv; bool q8; uint64_t nodes; std::string err;
+      Bx walk(int32_t ref, uint32_t depth) {
         Bx r;
         for (int a = 0; a < 3; ++a) r.lo[a] = 3e38f, r.hi[a] = -3e38f;
+        depthSeen = std::max(depthSeen, depth);
         if (ref < 0) {  // leaf: ~(byte offset of the first record | count - 1)
-          const uint32_t code = ~(uint32_t)ref, cnt = (code & 7u) + 1u, first = (code & ~7u) / 48u;
-          if ((code & ~7u) % 48u) err = "leaf offset is not a multiple of 48";
-          for (uint32_t i = first; i < first + cnt && err.empty(); ++i) {
-            if (i >= seen.size()) { err = "leaf range beyond the triangle array"; break; }
-            seen[i]++;
-            const uint32_t id = b.tris[i].id;
+          const uint32_t code = ~(uint32_t)ref, cnt = (code & 7u) + 1u;
+          if (cnt > b.leafMax) err = "leaf holds more records than leaf_max";
+          for (uint32_t t = 0; t < cnt && err.empty(); ++t) {
+            rtbvh::TriRec rec;
+            if (q8) {  // the records sit in the unified array: identify them by their id, compare with the leaf-order array
+              const size_t slot = ((size_t)(code & ~7u) >> 4) + 3u * t;
+              if (((code & ~7u) & 15u) || slot + 3 > b.q8.size()) { err = "leaf offset outside the unified array"; break; }
+              for (int k = 0; k < 3; ++k)
+                if (visited[slot + k]++) err = "a triangle slot is referenced twice";
+              memcpy(&rec, &b.q8[slot], sizeof rec);
+              if (rec.id >= seen.size() || memcmp(&rec, &b.trisRef[rec.id], sizeof rec) != 0) { err = "a triangle record of the unified array is not the scene's"; break; }
+              seen[rec.id]++;
+            } else {
+              const uint32_t i = (code & ~7u) / 48u + t;
+              if ((code & ~7u) % 48u) err = "leaf offset is not a multiple of 48";
+              if (i >= seen.size()) { err = "leaf range beyond the triangle array"; break; }
+              seen[i]++;
+              rec = b.tris[i];
+            }
             for (int k = 0; k < 3; ++k) {
-              const float* q = sc.vertex_pos + 3 * (size_t)sc.tri_vtx[3 * (size_t)id + k];
+              const float* q = sc.vertex_pos + 3 * (size_t)sc.tri_vtx[3 * (size_t)rec.id + k];
               for (int a = 0; a < 3; ++a) r.lo[a] = std::min(r.lo[a], q[a]), r.hi[a] = std::max(r.hi[a], q[a]);
             }
           }
           return r;
         }
-        if (ref % 64) { err = "inner ref is not a multiple of 64"; return r; }
-        const uint32_t idx = (uint32_t)ref / 64u;
-        if (idx >= visited.size()) { err = "inner ref beyond the node array"; return r; }
-        if (visited[idx]++) { err = "wide node reached twice"; return r; }
-        const rtbvh::Node4x16& n = b.nodes4[idx];
-        int k = 0;
-        while (k < 4 && !(n.box[k][0] == 0x7bffu && n.box[k][1] == 0xfbffu)) ++k;
-        for (int i = k; i < 4; ++i) {
-          for (int a = 0; a < 3; ++a)
-            if (n.box[i][2 * a] != 0x7bffu || n.box[i][2 * a + 1] != 0xfbffu) err = "unused slot is not the inverted box";
-          if (n.child[i] != n.child[0]) err = "unused slot does not repeat slot 0's ref";
+        float lo[2][3], hi[2][3];
+        int32_t child[2];
+        if (q8) {
+          if ((size_t)((uint32_t)ref >> 4) >= visited.size()) { err = "inner ref beyond the unified array"; return r; }
+          if (visited[(uint32_t)ref >> 4]++) { err = "node reached twice"; return r; }
+          rtbvh::decodeQ8(b, (uint32_t)ref, lo, hi, child);
+        } else {
+          if (ref % 32) { err = "inner ref is not a multiple of 32"; return r; }
+          const uint32_t idx = (uint32_t)ref / 32u;
+          if (idx >= visited.size()) { err = "inner ref beyond the node array"; return r; }
+          if (visited[idx]++) { err = "node reached twice"; return r; }
+          const rtbvh::Node16& n = b.nodes16[idx];
+          for (int i = 0; i < 2; ++i) {
+            const uint16_t* q = i ? n.box1 : n.box0;
+            for (int a = 0; a < 3; ++a) lo[i][a] = rtbvh::halfToFloat(q[2 * a]) * inv, hi[i][a] = rtbvh::halfToFloat(q[2 * a + 1]) * inv;
+            child[i] = n.child[i];
+          }
         }
-        if (k < 2) err = "wide node with fewer than two children";
-        kcount[k]++;
-        maxStack = std::max(maxStack, used + (uint32_t)k - 1u);
-        for (int i = 0; i < k && err.empty(); ++i) {
-          const Bx c = walk(n.child[i], used + (uint32_t)k - 1u);
+        ++nodes;
+        for (int i = 0; i < 2 && err.empty(); ++i) {
+          const Bx c = walk(child[i], depth + 1u);
+          if (child[i] >= 0) {
+            const double dx = (double)hi[i][0] - lo[i][0], dy = (double)hi[i][1] - lo[i][1], dz = (double)hi[i][2] - lo[i][2];
+            areaSum += dx * dy + dy * dz + dz * dx;
+          }
           for (int a = 0; a < 3; ++a) {
-            const float lo = rtbvh::halfToFloat(n.box[i][2 * a]) * inv, hi = rtbvh::halfToFloat(n.box[i][2 * a + 1]) * inv;
             // the stored box must contain the geometry below it, padded
-            if (!(lo <= c.lo[a] - 0.999f * b.pad && hi >= c.hi[a] + 0.999f * b.pad)) err = "a wide child box does not contain its padded geometry";
+            if (!(lo[i][a] <= c.lo[a] - 0.999f * b.pad && hi[i][a] >= c.hi[a] + 0.999f * b.pad)) err = "a child box does not contain its padded geometry";
             r.lo[a] = std::min(r.lo[a], c.lo[a]), r.hi[a] = std::max(r.hi[a], c.hi[a]);
           }
         }
         return r;
       }
-    } W{*sc, b, seen, visited, kcount, maxStack, inv, {}};
-    W.walk(0, 0);
-    if (!W.err.empty()) return fail(RT_ERR_STATE, "wide BVH check: %s", W.err.c_str());
+    } W{*sc, b, seen, visited, depthSeen, areaSum, inv, q8, 0, {}};
+    W.walk(q8 ? (int32_t)rtbvh::kQ8RootOffset : 0, 0);
+    if (!W.err.empty()) return fail(RT_ERR_STATE, "BVH check: %s", W.err.c_str());
     // (a one-triangle scene has that triangle under both children of its root: bvh_build.cpp build())
     for (uint32_t v : seen)
-      if (v != 1 && !(sc->n_triangles == 1 && v == 2)) return fail(RT_ERR_STATE, "wide BVH check: a triangle record is referenced %u times", v);
-    for (uint8_t v : visited)
-      if (v != 1) return fail(RT_ERR_STATE, "wide BVH check: an unreachable wide node");
-    if (maxStack != b.stackNeed4) return fail(RT_ERR_STATE, "wide BVH check: stack need %u, builder says %u", maxStack, b.stackNeed4);
-    const uint32_t allowed = std::max(stack_budget, b.maxDepth);
-    if (maxStack > allowed) return fail(RT_ERR_STATE, "wide BVH check: stack need %u exceeds the budget %u", maxStack, allowed);
-    out8[0] = (uint32_t)b.nodes.size(), out8[1] = (uint32_t)nw, out8[2] = b.stackNeed4, out8[3] = b.maxDepth;
-    out8[4] = kcount[4], out8[5] = kcount[3], out8[6] = kcount[2], out8[7] = 0;
-    if (est2) est2[0] = b.visitCost2, est2[1] = b.visitCost4;
+      if (v != 1 && !(sc->n_triangles == 1 && v == 2)) return fail(RT_ERR_STATE, "BVH check: a triangle record is referenced %u times", v);
+    if (W.nodes != nn) return fail(RT_ERR_STATE, "BVH check: %llu of %zu nodes reachable", (unsigned long long)W.nodes, nn);
+    if (depthSeen != b.maxDepth) return fail(RT_ERR_STATE, "BVH check: deepest leaf at level %u, builder says %u", depthSeen, b.maxDepth);
+    if ((int)depthSeen > b.depthCap) return fail(RT_ERR_STATE, "BVH check: depth %u exceeds the cap %d", depthSeen, b.depthCap);
+    out8[0] = (uint32_t)nn, out8[1] = (uint32_t)b.q8.size(), out8[2] = b.q8Blocks, out8[3] = b.maxDepth;
+    out8[4] = out8[5] = out8[6] = out8[7] = 0;
+    // the surface-area estimate of node visits per random ray: the root plus every inner child by its box area
+    if (est2) {
+      auto area = [](const float* lo, const float* hi) {
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+      };
+      const rtbvh::Node& n0 = b.nodes[0];
+      float lo[3], hi[3];
+      for (int a = 0; a < 3; ++a) lo[a] = std::min(n0.lo0[a], n0.lo1[a]), hi[a] = std::max(n0.hi0[a], n0.hi1[a]);
+      const double rootArea = std::max(area(lo, hi), 1e-300);
+      double v = 0;
+      for (const rtbvh::Node& n : b.nodes) {
+        if (n.child[0] >= 0) v += area(n.lo0, n.hi0);
+        if (n.child[1] >= 0) v += area(n.lo1, n.hi1);
+      }
+      est2[0] = 1.0 + v / rootArea, est2[1] = 1.0 + areaSum / rootArea;
+    }
   } catch (const std::exception& e) {
-    return fail(RT_ERR_INVALID, "wide BVH check failed: %s", e.what());
+    return fail(RT_ERR_INVALID, "BVH check failed: %s", e.what());
   }
   return RT_OK;
 }
@@ -1003,8 +1039,8 @@ int rt_bvh_wide_check_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t 
 int rt_bvh_tune(rt_ctx* c, const rt_params* probe, double budget_seconds, uint32_t max_probes, rt_tune_report* out) {
   if (!c || !probe) return fail(RT_ERR_INVALID, "ctx/probe is null");
   if (out) memset(out, 0, sizeof *out);
-  if (c->builder != RT_BVH_HOST || c->bvh.nodes.empty() || !c->bvh.nodes4.empty())
-    return fail(RT_ERR_STATE, "rt_bvh_tune needs a host-built binary tree");
+  if (c->builder != RT_BVH_HOST || c->bvh.nodes.empty() || c->nodeFormat != RT_NODES_F16)
+    return fail(RT_ERR_STATE, "rt_bvh_tune needs a host-built tree in the RT_NODES_F16 format");
   if (probe->use_photons || probe->accel != RT_ACCEL_BVH) return fail(RT_ERR_INVALID, "the probe must be a BVH render without the photon map");
   int rc = check_params(c, probe);
   if (rc != RT_OK) return rc;

@@ -21,6 +21,7 @@ enum {
   RTK_CNT_WLEAF,  // wave-level leaf phases
   RTK_CNT_LWAIT,  // lanes holding a leaf, summed over the wave-level node steps
   RTK_CNT_LIDLE,  // lanes without a ray, summed over the wave-level node steps
+  RTK_CNT_FRAMES, // Q8 node format: block frames fetched
   RTK_CNT_COUNT = 32  // [16..31]: section clocks of the diagnostic build (RT_PHASE_TIMING)
 };
 
@@ -29,7 +30,9 @@ namespace rtk {
 // Device-resident flattened scene (all pointers are HBM allocations of rt_ctx).
 struct DevScene {
   const uint4* nodes;      // n_nodes x 32 B: 12 x f16 box planes ((lo, hi) per axis, child 0 then child 1, scaled) + 2 child refs
-  const uint4* nodes4;     // wide form of the same tree (rtbvh::Node4x16, n_nodes4 x 64 B: 4 x 6 f16 planes + 4 refs), or null
+  const uint4* q8;         // the one-request form (rtbvh::Slot16: frames, 16-B node records and triangle records in one array), or null:
+                           // when set, the pooled render kernel and k_trace traverse it instead of nodes / tris
+  uint32_t q8ShiftBytes;   // log2 of a block's BYTES (rtbvh::Built::q8Shift + 4)
   const float4* tris;      // n_tris x 48 B, BVH leaf order: {p0,e1.x}{e1.yz,e2.xy}{e2.z,id,mesh,-}
   const float4* trisRef;   // same records in reference (mesh,tri) order (brute-force path)
   const uint4* triShade;   // per global triangle id: {v0,v1,v2 (global vertex ids), mesh}
@@ -42,13 +45,8 @@ struct DevScene {
   const float4* phPos;     // photons in kd-tree order: xyz + pad
   const float4* phDir;     // income direction xyz + weight
   uint32_t n_tris, n_nodes, n_lights, n_photons;
-  uint32_t n_nodes4;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
   uint32_t topK;           // node records [0, topK) are LDS-resident in the persistent kernel (set per launch)
-  // short stack (pooled persistent kernel on deep trees; set per launch)
-  uint32_t ssRows;         // stack entries kept in LDS (0 = the whole stack is in LDS)
-  uint32_t ssOvRows;       // rows of a lane's overflow column
-  uint32_t* ssOver;        // [wave slot][ssOvRows][64] overflow columns in HBM
   float originBound;       // k_trace: rays starting farther out run the exhaustive loop (rtbvh::Built)
   uint32_t leafT;          // Trav::round leaves its descent when fewer lanes than this still descend ...
   uint32_t leafMul;        // ... and fewer than leafMul/64 of the wave's live lanes
@@ -64,7 +62,6 @@ struct RenderArgs {
   uint32_t width, height, spp, s0, s1, mode, max_depth, seed, k, photons_requested;
   uint32_t flags;         // bit 0: shadow rays through the wave-level pool
   uint32_t stackLevels;   // LDS traversal-stack entries per lane (BVH depth; kd depth + 1 with photons)
-  uint32_t stackLevelsWide;  // the same for the wide tree (its stack need + the sentinel row + 2 rows the step writes ahead)
   uint32_t sshift;        // a wave = (64 >> sshift) pixels x (1 << sshift) samples side by side
   uint32_t tileW, tileH;  // pixel footprint of one wave (tileW * tileH == 64 >> sshift)
   uint32_t tilesPerBlock; // one-wave-per-workgroup kernels (k_render): consecutive wave tiles a workgroup renders (launcher)
@@ -72,7 +69,6 @@ struct RenderArgs {
   uint32_t* tileCounter;  // next wave tile to hand out (zeroed before the launch)
   uint32_t waveWords;     // LDS words per wave (stack levels x 64 + pool), set by the launcher
   uint32_t numCUs;        // workgroups to launch (one per CU)
-  uint32_t* ssOver;       // short-stack overflow buffer of the context (numCUs x 16 waves x 32 rows x 64 words)
 };
 
 hipError_t launch_render(bool brute_force, bool photon, bool stats, const DevScene& S, const RenderArgs& A,
@@ -90,7 +86,6 @@ struct WfArgs {
   float4 *org, *dir;     // [P] current ray
   uint2* key;            // [P] current hit {t bits, triangle id}; {~0, ~0}: the path has ended
   float4 *nrm, *pnt;     // [P] vertex normal (+ mesh in w), point
-  float4* knn;           // [P] photon-map shading: {sum of the k photon directions, distance of the k-th} (k_knn_stream)
   float4* col;           // [3][P] vertex colours; col[0].w: primary hit, col[1].w: slot holds a sample
   float4 *rayO, *rayD;   // [4P] ray queue
   uint2* res;            // [4P] results
@@ -99,8 +94,6 @@ struct WfArgs {
 hipError_t launch_wavefront(const DevScene& S, const WfArgs& W, uint32_t mode, uint32_t maxDepth, float4* accum,
                             unsigned long long* counters, uint32_t* queueCounter, uint32_t stackLevels, uint32_t numCUs,
                             hipStream_t stream);
-hipError_t launch_wavefront_photon(const DevScene& S, const WfArgs& W, uint32_t k, uint32_t photonsRequested, float4* accum,
-                                   unsigned long long* counters, uint32_t* queueCounter, uint32_t numCUs, hipStream_t stream);
 // ray queue in HBM -> results (wavefront stage T)
 hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const float4* rayD, uint32_t n, uint2* res,
                                uint32_t* counter, uint32_t stackLevels, uint32_t numCUs, hipStream_t stream);

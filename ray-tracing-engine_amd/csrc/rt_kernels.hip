@@ -40,7 +40,6 @@ constexpr int STACK = rtbvh::kMaxDepth;  // 32 words per lane
 constexpr int KMAX = RTK_KMAX;           // photon heap capacity per lane
 
 struct Lds {
-  uint32_t* over = nullptr;  // short stack: this lane's overflow column in HBM
   uint32_t* stack;  // [STACK][BLOCK] this thread's column: stack[level * BLOCK]
   uint2* heap;      // [KMAX][BLOCK] {distance bits, photon index}
 };
@@ -68,6 +67,7 @@ struct LaneStats {
   uint32_t closest = 0, shadow = 0, knn = 0, nodes = 0, tris = 0, kd = 0;
   uint32_t wnode = 0, wleaf = 0;  // wave-level node steps / leaf phases (counted by the first active lane)
   uint32_t lwait = 0, lidle = 0;  // lanes holding a leaf / no ray during those node steps
+  uint32_t frames = 0;            // Q8: block frames fetched
 };
 
 struct HitRec {
@@ -94,6 +94,11 @@ RT_DEV f3 f4xyz(const float4& a) { return mk(a.x, a.y, a.z); }
 // units (pad*|inv|, pad >= 6e-5*|o|max), so no padded box is ever wrongly culled.
 RT_DEV float h2f_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
 RT_DEV float h2f_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+// byte k of a word as a float: the compiler selects v_cvt_f32_ubyteK (extract + convert, one instruction)
+RT_DEV float ub0(uint32_t w) { return (float)(w & 0xffu); }
+RT_DEV float ub1(uint32_t w) { return (float)((w >> 8) & 0xffu); }
+RT_DEV float ub2(uint32_t w) { return (float)((w >> 16) & 0xffu); }
+RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 
 RT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 inv, f3 oi, float tmax,
                  float& tn) {
@@ -163,11 +168,13 @@ constexpr int TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_MIXED = 2;  // MIXED: per-lan
 // LT: where node records live.  LT_NONE: HBM/L2 through the vector L1; LT_TOP: records
 // [0, S.topK) in LDS (g_lds), the rest in HBM/L2; LT_ALL: the whole tree in LDS.
 constexpr int LT_NONE = 0, LT_TOP = 1, LT_ALL = 2;
-// + LT_SS: SHORT STACK.  Only the first S.ssRows entries of a lane's stack live in LDS; deeper
-// ones (rare: a ray's pending far children seldom exceed a dozen) spill to a per-lane column in
-// HBM.  A 21-level tree then costs a wave 13 rows of LDS instead of 22, which is what makes room
-// for the top of a big tree beside 16 waves.
-constexpr int LT_SS = 4;
+// + LT_Q8: the ONE-REQUEST node (rtbvh::Slot16, bvh_build.h): a 16-byte record — 12 8-bit box planes in the frame of the
+// record's 16-KiB block + one word that locates both children — in ONE array with the triangle records.  A visit is one
+// dwordx4 instead of two; a lane that enters a record of another block fetches that block's frame {origin, step} with it
+// (one more request, in flight together with the record) and rebuilds its two slab constants: t = q * (step / d) +
+// (origin - o) / d, so the 8-bit plane goes into the same fma the binary16 plane went into (v_cvt_f32_ubyteN extracts
+// and converts in one instruction, v_perm_b32 orders a word's two (lo, hi) pairs along the ray).
+constexpr int LT_Q8 = 4;
 // Wave priority by phase (s_setprio): a wave in the DESCENT (a chain of dependent LDS round trips
 // and short instruction runs) or in the pool bookkeeping issues ahead of waves that stream through
 // shading arithmetic or triangle tests, instead of queueing behind them by age.  Measured: C2
@@ -186,13 +193,6 @@ constexpr int LT_COMPACT = 16;
 // holds the direction anyway; a lane that steals part of a bounce ray takes the direction from the
 // victim's registers.  The eight-million-triangle scene's sixteenth wave.
 constexpr int LT_COMPACT2 = 32;
-// WIDE nodes (rtbvh::Node4x16): one 64-B record with four child boxes per step; the hit children are
-// sorted by entry distance, the nearest is entered, the others pushed far to near.  Half the DEPENDENT
-// fetches per ray: the lever on scenes whose nodes come from L2 / HBM.
-constexpr int LT_WIDE = 64;
-// CU-level ray sharing (vertex_pool_cus): a wave whose own pool has no rays left to hand out takes
-// fresh rays from the pools of the other waves of its workgroup instead of idling through its tail.
-constexpr int LT_CUS = 128;
 // 1 / det of the triangle test by rtd::recip_fast (3 instructions, the division's bits for |det| < 2^100) instead of the
 // division: only the instances the launcher picks when the host has bounded |det| for the launch's rays (DevScene::slowRecip == 0).
 constexpr int LT_FASTDET = 256;
@@ -203,17 +203,20 @@ typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
 template <int MODE, int LTX = LT_NONE>
 struct Trav {
   static constexpr int LT = LTX & 3;
-  static constexpr bool SS = (LTX & LT_SS) != 0;
   static constexpr bool PRIO = (LTX & LT_NOPRIO) == 0;
-  static constexpr bool WIDE = (LTX & LT_WIDE) != 0;
   static constexpr bool DIVIDE = (LTX & LT_FASTDET) == 0;
+  static constexpr bool Q8 = (LTX & LT_Q8) != 0;
+  static_assert(!Q8 || LT == LT_NONE, "Q8 records are fetched from HBM / L2");
   // any-hit rays enter child 0 (the smaller box) first: the big-scene instances and the whole-tree-in-LDS ones (measured:
   // C5 -2.5 %, C5x8 -1.9 %, C2 -0.7 %, C1 -3 %; the partial-top instance of C4 loses 0.7 % to the extra scalar op and keeps
   // the distance order)
-  static constexpr bool ANYORD = !WIDE && ((LTX & LT_NOPRIO) != 0 || LT == LT_ALL);
-  static_assert(!WIDE || (LT == LT_NONE && !SS), "wide nodes are fetched from HBM/L2 and use the plain LDS stack");
+  static constexpr bool ANYORD = (LTX & LT_NOPRIO) != 0 || LT == LT_ALL;
   f3 o, d, inv, oi;
-  uint32_t rotX, rotY, rotZ;  // 16 where the direction component is negative (order_planes)
+  uint32_t rotX, rotY, rotZ;  // 16 where the direction component is negative (order_planes); Q8: the v_perm_b32 selectors of the three plane words
+  // Q8: 1 / d (inv and oi then hold the slab constants IN THE HELD FRAME: step / d and (o - origin) / d) and the block
+  // whose frame that is
+  f3 inv0;
+  uint32_t fblk;
   float best;
   uint32_t bestId;
   bool found, anyHit;
@@ -222,10 +225,6 @@ struct Trav {
   // so no step ever tests for emptiness or clamps an index)
   uint32_t* top;
   uint32_t* base;
-  // short stack (SS): entries beyond row S.ssRows live at over[i * BLOCK], i < ov
-  uint32_t* over;
-  uint32_t* limit;  // base + ssRows * BLOCK: the last LDS row
-  int ov;
   int32_t cur;
   HitRec hit;
   // pool mode (TRAV_MIXED): several lanes may walk disjoint subtrees of ONE ray
@@ -241,27 +240,31 @@ struct Trav {
   // entries on the stack (live lanes only: top >= base there, so the byte distance is unsigned —
   // a signed 64-bit pointer difference and division cost seven instructions)
   RT_DEV int depth() const {
-    return (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)base) / (4u * BLOCK)) + (SS ? ov : 0);
+    return (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)base) / (4u * BLOCK));
   }
-  RT_DEV void idle(uint32_t* stack, uint32_t* overflow = nullptr, uint32_t ssRows = 0) {
-    cur = TERM, found = false, base = top = stack, stolen = 0, shared = false;
-    over = overflow, limit = stack + ssRows * BLOCK, ov = 0;
-  }
-  RT_DEV uint32_t peek() const { return (SS && ov) ? over[(ov - 1) * BLOCK] : *top; }
-  RT_DEV void pop() {
-    if (SS && ov) --ov;
-    else top -= BLOCK;
-  }
+  RT_DEV void idle(uint32_t* stack) { cur = TERM, found = false, base = top = stack, stolen = 0, shared = false; }
+  RT_DEV uint32_t peek() const { return *top; }
+  RT_DEV void pop() { top -= BLOCK; }
   RT_DEV void start(f3 o_, f3 d_, float invScale) {
     o = o_, d = d_;
     const f3 i1 = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-    oi = mk(o.x * i1.x, o.y * i1.y, o.z * i1.z);
-    // boxes are stored as coordinate * boxScale (a power of two): fold 1/boxScale in
-    inv = mk(i1.x * invScale, i1.y * invScale, i1.z * invScale);
-    rotX = (__float_as_uint(i1.x) >> 31) << 4, rotY = (__float_as_uint(i1.y) >> 31) << 4, rotZ = (__float_as_uint(i1.z) >> 31) << 4;
+    if (Q8) {
+      inv0 = i1, fblk = ~0u;  // (no frame held: the first step fetches the root block's)
+      inv = oi = mk(0.f, 0.f, 0.f);
+      // a plane word holds two (lo, hi) byte pairs — (x, y) of child 0, (z of child 0, x of child 1), (y, z) of child 1 —
+      // and v_perm_b32 swaps the bytes of a pair whose axis the ray runs against
+      const uint32_t nx = __float_as_uint(i1.x) >> 31, ny = __float_as_uint(i1.y) >> 31, nz = __float_as_uint(i1.z) >> 31;
+      rotX = 0x03020100u ^ (nx * 0x00000101u) ^ (ny * 0x01010000u);
+      rotY = 0x03020100u ^ (nz * 0x00000101u) ^ (nx * 0x01010000u);
+      rotZ = 0x03020100u ^ (ny * 0x00000101u) ^ (nz * 0x01010000u);
+    } else {
+      oi = mk(o.x * i1.x, o.y * i1.y, o.z * i1.z);
+      // boxes are stored as coordinate * boxScale (a power of two): fold 1/boxScale in
+      inv = mk(i1.x * invScale, i1.y * invScale, i1.z * invScale);
+      rotX = (__float_as_uint(i1.x) >> 31) << 4, rotY = (__float_as_uint(i1.y) >> 31) << 4, rotZ = (__float_as_uint(i1.z) >> 31) << 4;
+    }
     best = 3.402823466e+38f;  // numeric_limits<float>::max(), RayTracer.h:30
-    bestId = 0, found = false, top = base, cur = 0, stolen = 0, shared = false;
-    ov = 0;
+    bestId = 0, found = false, top = base, cur = Q8 ? (int32_t)rtbvh::kQ8RootOffset : 0, stolen = 0, shared = false;
     *base = (uint32_t)TERM;
     // A ray with a NaN component cannot hit anything: Ray.cpp:9-24 then yields NaN u
     // or v for every triangle and every comparison fails (hemisphere samples are NaN
@@ -297,8 +300,39 @@ struct Trav {
     if (PRIO) __builtin_amdgcn_s_setprio(2);
     if (inner) for (;;) {
      if (__builtin_amdgcn_inverse_ballot_w64(inner)) {
-      if constexpr (WIDE) {
-        step_wide<STATS>(S, st, statWait, statIdle);
+      {
+      float t0, t1;
+      bool h0, h1;
+      int2 ch;
+      int32_t below;
+      if (STATS) {
+        st.nodes++;
+        if (__ffsll((long long)wave_ballot(true)) - 1 == (int)(threadIdx.x & 63)) st.wnode++, st.lwait += statWait, st.lidle += statIdle;
+      }
+      if constexpr (Q8) {
+        // ONE request: the 16-byte record; plus its block's frame when the lane last decoded a record of another block
+        const char* const q8 = reinterpret_cast<const char*>(S.q8);
+        const uint4 r = *reinterpret_cast<const uint4*>(q8 + (uint32_t)cur);
+        const uint32_t blk = (uint32_t)cur >> S.q8ShiftBytes;
+        if (blk != fblk) {
+          const float4 fr = *reinterpret_cast<const float4*>(q8 + (blk << S.q8ShiftBytes));
+          inv = mk(inv0.x * fr.w, inv0.y * fr.w, inv0.z * fr.w);
+          oi = mk((o.x - fr.x) * inv0.x, (o.y - fr.y) * inv0.y, (o.z - fr.z) * inv0.z);
+          fblk = blk;
+          if (STATS) st.frames++;
+        }
+        PHC(PH_N_STEPS);
+        below = (int32_t)peek();
+        // both children's items are adjacent, child 0's first: one word locates them (bvh_build.h Slot16)
+        const uint32_t ref = r.w, base0 = ref & ~15u;
+        const uint32_t base1 = base0 + ((ref & 1u) ? ((ref & 4u) ? 96u : 48u) : 16u);
+        ch.x = (ref & 1u) ? (int32_t)~(base0 | ((ref >> 2) & 1u)) : (int32_t)base0;
+        ch.y = (ref & 2u) ? (int32_t)~(base1 | ((ref >> 3) & 1u)) : (int32_t)base1;
+        const uint32_t w0 = __builtin_amdgcn_perm(r.x, r.x, rotX), w1 = __builtin_amdgcn_perm(r.y, r.y, rotY), w2 = __builtin_amdgcn_perm(r.z, r.z, rotZ);
+        h0 = slab_ordered(ub0(w0), ub1(w0), ub2(w0),
+                          ub3(w0), ub0(w1), ub1(w1), inv, oi, best, t0);
+        h1 = slab_ordered(ub2(w1), ub3(w1), ub0(w2),
+                          ub1(w2), ub2(w2), ub3(w2), inv, oi, best, t1);
       } else {
       // 32-B packed node: 12 x f16 planes + 2 refs (32-bit byte offset from a uniform base:
       // the load takes the base from SGPRs)
@@ -326,17 +360,13 @@ struct Trav {
       PHC(PH_N_STEPS);
       // the entry a miss would pop, fetched with the node (its latency hides behind the
       // node's; a read in the divergent pop branch made every step wait for LDS)
-      const int32_t below = (int32_t)peek();
-      const int2 ch = make_int2((int)b.z, (int)b.w);
-      if (STATS) {
-        st.nodes++;
-        if (__ffsll((long long)wave_ballot(true)) - 1 == (int)(threadIdx.x & 63)) st.wnode++, st.lwait += statWait, st.lidle += statIdle;
-      }
-      float t0, t1;
+      below = (int32_t)peek();
+      ch = make_int2((int)b.z, (int)b.w);
       const uint32_t x0 = order_planes(a.x, rotX), y0 = order_planes(a.y, rotY), z0 = order_planes(a.z, rotZ);
       const uint32_t x1 = order_planes(a.w, rotX), y1 = order_planes(b.x, rotY), z1 = order_planes(b.y, rotZ);
-      const bool h0 = slab_ordered(h2f_lo(x0), h2f_hi(x0), h2f_lo(y0), h2f_hi(y0), h2f_lo(z0), h2f_hi(z0), inv, oi, best, t0);
-      const bool h1 = slab_ordered(h2f_lo(x1), h2f_hi(x1), h2f_lo(y1), h2f_hi(y1), h2f_lo(z1), h2f_hi(z1), inv, oi, best, t1);
+      h0 = slab_ordered(h2f_lo(x0), h2f_hi(x0), h2f_lo(y0), h2f_hi(y0), h2f_lo(z0), h2f_hi(z0), inv, oi, best, t0);
+      h1 = slab_ordered(h2f_lo(x1), h2f_hi(x1), h2f_lo(y1), h2f_hi(y1), h2f_lo(z1), h2f_hi(z1), inv, oi, best, t1);
+      }
       // select-based step: one divergent branch (the pop) instead of a four-way chain;
       // the far child is stored unconditionally (the slot is simply not claimed unless
       // both children were hit)
@@ -347,23 +377,9 @@ struct Trav {
       const uint64_t mle = ANYORD ? (__builtin_amdgcn_ballot_w64(t0 <= t1) | anyFirst) : __builtin_amdgcn_ballot_w64(t0 <= t1);
       const bool takeY = __builtin_amdgcn_inverse_ballot_w64(m1 & ~(m0 & mle));
       const bool both = __builtin_amdgcn_inverse_ballot_w64(m0 & m1), any = __builtin_amdgcn_inverse_ballot_w64(m0 | m1);
-      if (SS) {
-        const bool full = top == limit;  // the LDS rows are used up: this entry goes to HBM
-        const uint32_t far = (uint32_t)(takeY ? ch.x : ch.y);
-        if (full) over[ov * BLOCK] = far;
-        else top[BLOCK] = far;
-        cur = any ? (takeY ? ch.y : ch.x) : below;
-        if (both) {
-          if (full) ++ov;
-          else top += BLOCK;
-        } else if (!any) {
-          pop();
-        }
-      } else {
-        top[BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
-        cur = any ? (takeY ? ch.y : ch.x) : below;
-        top += both ? BLOCK : any ? 0 : -BLOCK;  // (a lane that pops the sentinel is dead until start())
-      }
+      top[BLOCK] = (uint32_t)(takeY ? ch.x : ch.y);
+      cur = any ? (takeY ? ch.y : ch.x) : below;
+      top += both ? BLOCK : any ? 0 : -BLOCK;  // (a lane that pops the sentinel is dead until start())
       // leave the descent early once only a few lanes are still descending: they
       // sit out one leaf phase (masked) instead of making everyone else wait for them
       // (only when the lanes that would otherwise wait clearly outnumber them: in the
@@ -380,7 +396,7 @@ struct Trav {
       const uint32_t code = ~(uint32_t)cur;
       // (byte offset of the leaf's first record | count - 1: the loads take the base from SGPRs)
       const uint32_t cnt = (code & 7u) + 1u;
-      const char* const leaf = reinterpret_cast<const char*>(S.tris) + (code & ~7u);
+      const char* const leaf = reinterpret_cast<const char*>(Q8 ? reinterpret_cast<const float4*>(S.q8) : S.tris) + (code & ~7u);
       if (STATS) st.wleaf += (uint32_t)(__ffsll((long long)wave_ballot(true)) - 1 == (int)(threadIdx.x & 63));
       // leaves hold 1..leaf_max (default 2) records: the first two are tested in
       // straight-line code with both records' loads in flight together
@@ -398,63 +414,6 @@ struct Trav {
     }
     if (PRIO && MODE == TRAV_MIXED) __builtin_amdgcn_s_setprio(1);  // back in the pool loop
     PH(PH_LEAF);
-  }
-
-  // One step on a WIDE node (rtbvh::Node4x16): four slab tests on one 64-B record (4 x dwordx4 from
-  // one half cache line), the hit children ordered by entry distance with a five-comparator network
-  // (key = entry distance, -1 for a miss: descending order puts the hits first, far to near), the
-  // three farthest stored unconditionally above the top (rows the stack is sized for; a row that is
-  // not claimed is simply overwritten later), the nearest entered.  No hit: pop, as in the binary step.
-  template <bool STATS>
-  RT_DEV void step_wide(const DevScene& S, LaneStats& st, uint32_t statWait, uint32_t statIdle) {
-    const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes4) + (uint32_t)cur);
-    const uint4 a = n[0], b = n[1], c = n[2], r = n[3];
-    PHC(PH_N_STEPS);
-    const int32_t below = (int32_t)peek();
-    if (STATS) {
-      st.nodes++;
-      if (__ffsll((long long)wave_ballot(true)) - 1 == (int)(threadIdx.x & 63)) st.wnode++, st.lwait += statWait, st.lidle += statIdle;
-    }
-    // child 0: a.x a.y a.z | child 1: a.w b.x b.y | child 2: b.z b.w c.x | child 3: c.y c.z c.w
-    float k0, k1, k2, k3;
-    {
-      const uint32_t x = order_planes(a.x, rotX), y = order_planes(a.y, rotY), z = order_planes(a.z, rotZ);
-      const bool h = slab_ordered(h2f_lo(x), h2f_hi(x), h2f_lo(y), h2f_hi(y), h2f_lo(z), h2f_hi(z), inv, oi, best, k0);
-      k0 = h ? k0 : -1.f;
-    }
-    {
-      const uint32_t x = order_planes(a.w, rotX), y = order_planes(b.x, rotY), z = order_planes(b.y, rotZ);
-      const bool h = slab_ordered(h2f_lo(x), h2f_hi(x), h2f_lo(y), h2f_hi(y), h2f_lo(z), h2f_hi(z), inv, oi, best, k1);
-      k1 = h ? k1 : -1.f;
-    }
-    {
-      const uint32_t x = order_planes(b.z, rotX), y = order_planes(b.w, rotY), z = order_planes(c.x, rotZ);
-      const bool h = slab_ordered(h2f_lo(x), h2f_hi(x), h2f_lo(y), h2f_hi(y), h2f_lo(z), h2f_hi(z), inv, oi, best, k2);
-      k2 = h ? k2 : -1.f;
-    }
-    {
-      const uint32_t x = order_planes(c.y, rotX), y = order_planes(c.z, rotY), z = order_planes(c.w, rotZ);
-      const bool h = slab_ordered(h2f_lo(x), h2f_hi(x), h2f_lo(y), h2f_hi(y), h2f_lo(z), h2f_hi(z), inv, oi, best, k3);
-      k3 = h ? k3 : -1.f;
-    }
-    uint32_t r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
-#define RT_CSWAP(ka, ra, kb, rb)                       \
-  do {                                                 \
-    const bool sw_ = ka < kb;                          \
-    const float kx_ = sw_ ? kb : ka, ky_ = sw_ ? ka : kb; \
-    const uint32_t rx_ = sw_ ? rb : ra, ry_ = sw_ ? ra : rb; \
-    ka = kx_, kb = ky_, ra = rx_, rb = ry_;            \
-  } while (0)
-    RT_CSWAP(k0, r0, k1, r1);
-    RT_CSWAP(k2, r2, k3, r3);
-    RT_CSWAP(k0, r0, k2, r2);
-    RT_CSWAP(k1, r1, k3, r3);
-    RT_CSWAP(k1, r1, k2, r2);
-#undef RT_CSWAP
-    top[BLOCK] = r0, top[2 * BLOCK] = r1, top[3 * BLOCK] = r2;
-    const bool e0 = k0 >= 0.f, e1 = k1 >= 0.f, e2 = k2 >= 0.f, e3 = k3 >= 0.f;
-    cur = e3 ? (int32_t)r3 : e2 ? (int32_t)r2 : e1 ? (int32_t)r1 : e0 ? (int32_t)r0 : below;
-    top += e3 ? 3 * BLOCK : e2 ? 2 * BLOCK : e1 ? BLOCK : e0 ? 0 : -BLOCK;  // (a lane that pops the sentinel is dead until start())
   }
 
   // The first two records of a leaf at once and without a branch: both tests run, every
@@ -529,10 +488,9 @@ struct Trav {
 //                only uses the bool)
 // `on` = this lane has a ray; lanes without one still take part in the wave loop.
 template <bool ANY, bool STATS, int LT = LT_NONE>
-RT_DEV bool traverse(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st,
-                     uint32_t* over = nullptr) {
+RT_DEV bool traverse(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
   Trav<ANY ? TRAV_ANY : TRAV_CLOSEST, LT> T;
-  T.idle(stack, over, S.ssRows);
+  T.idle(stack);
   if (on) T.start(o, d, S.invBoxScale);
   PH(PH_SETUP);
   while (wave_ballot(T.live()) != 0) {
@@ -566,10 +524,9 @@ RT_DEV bool brute(const DevScene& S, f3 o, f3 d, HitRec& hit, LaneStats& st) {
 
 // `on`: lanes without a ray pass false (wave-uniform call sites, no early exits).
 template <bool BRUTE, bool ANY, bool STATS, int LT = LT_NONE>
-RT_DEV bool cast(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st,
-                 uint32_t* over = nullptr) {
+RT_DEV bool cast(const DevScene& S, bool on, f3 o, f3 d, uint32_t* stack, HitRec& hit, LaneStats& st) {
   if (BRUTE) return on && brute<ANY, STATS>(S, o, d, hit, st);
-  return traverse<ANY, STATS, LT>(S, on, o, d, stack, hit, st, over);
+  return traverse<ANY, STATS, LT>(S, on, o, d, stack, hit, st);
 }
 
 // Renderer.cpp:274-277 dotArr: (w*a + u*b) + v*c per component
@@ -645,120 +602,7 @@ RT_DEV float photon_dist(const DevScene& S, uint32_t n, f3 p, float4& pos) {
   return dist3(mk(pos.x, pos.y, pos.z), p);
 }
 
-// kdtree::knearest (kdtree.h:87-107, 180-195) as a walk that can be advanced one node visit at a time: the fused
-// kernel runs it to the end per lane (knn_query), the query-stream kernel (k_knn_stream) refills a lane that has
-// finished with the next query while its neighbours are still walking.
-struct KnnWalk {
-  f3 p;
-  double bestdist;
-  float skip2;
-  uint32_t visited, pending, wentLeft, odd, b, e;
-  int level;
-  bool mono;
-  RT_DEV void init(const DevScene& S, f3 p_, int k, const Heap& H) {
-    p = p_;
-    float4 pos;
-    for (int j = 0; j < k; j++) H.set(j, photon_dist(S, (uint32_t)j, p, pos), (uint32_t)j);
-    H.make(k);
-    bestdist = (double)H.D(0);
-    skip2 = (float)(bestdist * bestdist * (1.0 + 1e-6));
-    visited = 0;
-    mono = k >= 2;  // m_bestdist is non-increasing (see the unwind below)
-    pending = 0, wentLeft = 0, odd = 0;
-    b = 0, e = S.n_photons;
-    level = 0;
-  }
-  // One kdtree::knearest(node*) activation: a lane whose range ran empty unwinds to its next owed far side inside the
-  // same call, so all lanes of the wave arrive at the next node visit together (with a nested descend-until-empty loop,
-  // lanes that reached the bottom early waited for the deepest descent of the wave).  Invariant at entry: b < e.
-  // Returns false when the walk is over.
-  RT_DEV bool step(const DevScene& S, int k, const Heap& H, float* dxStack) {
-    {
-      const uint32_t n = b + (e - b) / 2;
-      ++visited;
-      // kdtree.h:90-92 compares the fp32 distance sqrt(d2), widened, with m_bestdist.  The
-      // correctly rounded root is only taken when d2 is not clearly out: d2 >= skip2 =
-      // m_bestdist^2 * (1 + 1e-6) rounded to float implies sqrtf(d2) >= m_bestdist (a
-      // correctly rounded sqrt is monotone and within 6e-8 relative), i.e. no insert.
-      const float4 pos = S.phPos[n];
-      const f3 dv = mk(pos.x, pos.y, pos.z) - p;
-      const float d2 = dot3(dv, dv);
-      if (!(d2 >= skip2)) {
-        const float dn = __builtin_sqrtf(d2);
-        if ((double)dn < bestdist) {
-          H.pop(k);                       // pop_heap
-          bestdist = (double)H.D(0);      // front() of the remaining k-1, then pop_back
-          H.set(k - 1, dn, n);            // push_back(*root)
-          H.push_up(k - 1, 0, dn, n);     // push_heap
-          skip2 = (float)(bestdist * bestdist * (1.0 + 1e-6));
-        }
-      }
-      if (bestdist != 0) {
-        const int axis = level % 3;
-        const float pc = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
-        const float nc = axis == 0 ? pos.x : axis == 1 ? pos.y : pos.z;
-        const float dx = nc - pc;
-        const bool left = dx > 0.f;
-        // m_bestdist never increases (k >= 2), so a far side that both prunes below
-        // already reject now stays rejected: it is not even recorded
-        const double dxd = (double)dx;
-        if (!mono || (!(dxd * dxd >= bestdist) && !((dxd < 0 ? -dxd : dxd) * (1.0 - 4.8e-7) >= bestdist))) {
-          dxStack[level * BLOCK] = dx;
-          pending |= 1u << level;
-        }
-        wentLeft = left ? (wentLeft | (1u << level)) : (wentLeft & ~(1u << level));
-        odd = ((e - b) & 1u) ? (odd | (1u << level)) : (odd & ~(1u << level));
-        if (left) e = n;
-        else b = n + 1;
-        level++;
-        if (b < e) return true;  // descend
-      }
-    }
-    // unwind to the deepest activation that still owes its far-side check
-    bool resumed = false;
-    while (pending) {
-      const int L = 31 - __clz(pending);
-      pending &= ~(1u << L);
-      const double dx = (double)dxStack[L * BLOCK];
-      if (dx * dx >= bestdist) continue;  // kdtree.h:105 (squared vs plain distance, as there)
-      // Result-preserving extra prune.  Every photon of the far subtree lies beyond
-      // the split plane, so its float distance is >= |dx| * (1 - 1.5e-7) (monotone
-      // float subtraction; three roundings under the sqrt, one on it), and
-      // m_bestdist never increases: if |dx| already exceeds it, no node of that
-      // subtree can pass `d < m_bestdist` (kdtree.h:92) and the heap — hence the
-      // result — is the same whether or not the subtree is walked.  (Monotone for
-      // k >= 2: the new value is the second largest of the old heap plus the new point.
-      // With k = 1 "the remaining k-1" is empty and front() is the PREVIOUS insert, which
-      // may be larger than the one before it: there only the reference's own test runs.)  The reference's
-      // own test is much weaker whenever m_bestdist < 1 (it needs |dx| >= sqrt of it):
-      // 546 -> ~1/6 of the node visits on the C3 workload.
-      if (mono && (dx < 0 ? -dx : dx) * (1.0 - 4.8e-7) >= bestdist) continue;
-      // Walk the range back UP from the current level to level L (amortised O(1) per
-      // visit; rebuilding it from the root cost O(L) per resume).  A range of s nodes
-      // splits at n = b + s/2 into a left child of s/2 and a right child of s - s/2 - 1
-      // nodes, so a child range, the side taken and the parity of s give the parent:
-      for (int l = level - 1; l >= L; l--) {
-        const uint32_t o = (odd >> l) & 1u;
-        if (wentLeft & (1u << l)) e = b + 2u * (e - b) + o;       // left child [b, n)
-        else b = e - (2u * (e - b) + 2u - o);                     // right child [n+1, e)
-      }
-      // ... and take the far child of the level-L node
-      const uint32_t m = b + (e - b) / 2;
-      if (wentLeft & (1u << L)) b = m + 1, wentLeft &= ~(1u << L);
-      else e = m, wentLeft |= (1u << L);
-      level = L + 1;
-      if (b >= e) continue;  // that side is empty: the activation returns at once (kdtree.h:88)
-      resumed = true;
-      break;
-    }
-    return resumed;
-  }
-};
-
 // After the call the heap holds the k results in ascending distance order.
-// (The walk of KnnWalk above, run to its end in one loop: kept as ONE function because the fused photon kernel is 2 %
-// faster this way than through KnnWalk::step; tests/test_gpu_parity.py test_photon_query_stream_option_is_exact holds
-// the two against each other bit for bit.)
 RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* dxStack) {
   float4 pos;
   for (int j = 0; j < k; j++) H.set(j, photon_dist(S, (uint32_t)j, p, pos), (uint32_t)j);
@@ -968,8 +812,7 @@ static_assert(VP_WORDS == (int)rtbvh::kWavePoolWords && BLOCK == (int)rtbvh::kSt
 
 template <bool STATS, int LT>
 RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
-                      f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
-                      uint32_t* over = nullptr) {
+                      f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
   constexpr bool FR = (LT & LT_FASTDET) != 0;  // 1 / length by rtd::recip_fast (see rtd::unit3)
   const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
   constexpr bool CP2 = (LT & LT_COMPACT2) != 0, CP = CP2 || (LT & LT_COMPACT) != 0;
@@ -1020,7 +863,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   const uint32_t kinds = nl + (bounce ? 1u : 0u), R = n * kinds;
   uint32_t head = 0, myK = 0, myJ = 0;
   Trav<TRAV_MIXED, LT> T;
-  T.idle(stack, over, S.ssRows);
+  T.idle(stack);
   T.sharedKey = keys, T.pj = 0;
   uint32_t* stackBase = stack - lane;
   if (!(LT & LT_NOPRIO)) __builtin_amdgcn_s_setprio(1);
@@ -1075,9 +918,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       // victim's registers.
       uint16_t* list16 = reinterpret_cast<uint16_t*>(list);
       uint32_t given = 0;
-      // entries this lane could hand over (short stack: only those resident in LDS)
-      int avail = T.live() ? T.depth() - T.stolen : 0;
-      if (LT & LT_SS) avail = min(avail, (int)S.ssRows - T.stolen);
+      // entries this lane could hand over
+      const int avail = T.live() ? T.depth() - T.stolen : 0;
       // (the passes only write the list; the lane's own state changes once, after them —
       // per-lane flags updated inside a loop with exits cost a dozen mask instructions per pass)
       int gave = 0;
@@ -1193,308 +1035,6 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   return color;
 }
 
-// ---------------------------------------------------------------- vertex pool with CU-level ray sharing
-// The 16 waves of a persistent workgroup run their pools at different phases: while one wave is in
-// its tail (its last long rays on a handful of lanes, nothing left to hand out) others still have
-// more rays than lanes.  Here a wave in that state takes FRESH rays from another wave's pool: every
-// pool has a descriptor in the workgroup's control block —
-//   [0] claim word   generation << 16 | next rank to hand out   (owner: atomic add; others: CAS on
-//                    the word they validated, so a claim can never land in a later generation)
-//   [1] info         R | n << 9 | n_lights << 16 | bounce << 18
-//   [2] fdone        rays finished by OTHER waves' lanes (their results are already in the pool)
-// — and the control block's word 0 is the mask of pools that still have unclaimed rays.  A foreign
-// lane reads the ray from the owner's pool, walks it, writes the result where the owner's own lanes
-// would (the occlusion bit by atomic or, the bounce key by atomic min) and counts it in fdone; the
-// owner leaves its pool loop when its own lanes are done AND fdone equals the rays it did not claim
-// itself.  Rays taken by another wave are walked by exactly one lane (in-wave stealing only splits
-// a wave's own rays), so "finished" is well defined.  Everything is LDS traffic between waves of one
-// CU: per-wave DS order + workgroup-scope fences, no barrier.  Results are bit-identical: who walks a
-// ray never mattered.
-constexpr int CU_AVAIL = 0, CU_DESC = 4, CU_DESC_WORDS = 4;
-static_assert(CU_DESC + 16 * CU_DESC_WORDS <= (int)rtbvh::kCtlWords, "control block");
-
-RT_DEV uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-template <bool STATS, int LT>
-RT_DEV f3 vertex_pool_cus(const DevScene& S, bool alive, bool bounce, Rng& g, f3 rayDir, uint32_t mesh, f3 hitNormal,
-                          f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st,
-                          uint32_t* ctl, uint32_t wv, int32_t waveWords, uint32_t& gen) {
-  constexpr bool FR = (LT & LT_FASTDET) != 0;  // 1 / length by rtd::recip_fast (see rtd::unit3)
-  static_assert(!(LT & (LT_COMPACT2 | LT_SS | LT_WIDE)), "CU sharing: full or light-parameter pools, plain stack, binary nodes");
-  const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
-  constexpr bool CP = (LT & LT_COMPACT) != 0;
-  using VP = VpLayout<CP ? 1 : 0>;
-  float* fp = reinterpret_cast<float*>(pool);
-  uint32_t* list = pool + VP::LIST;
-  uint8_t* listB = reinterpret_cast<uint8_t*>(list);
-  uint32_t* res = pool + VP::RES;
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(pool + VP::KEY);
-  const uint64_t amask = wave_ballot(alive);
-  const uint32_t n = (uint32_t)__popcll(amask);
-  f3 color = mk(0.f, 0.f, 0.f);
-  nextFound = false;
-  if (n == 0) return color;
-  PH(PH_VSETUP);
-  PHC(PH_N_POOLS);
-  if (alive) {
-    fp[VP_PT + lane] = point.x, fp[VP_PT + 64 + lane] = point.y, fp[VP_PT + 128 + lane] = point.z;
-    for (uint32_t l = 0; l < nl; l++) {
-      if (CP) {
-        float rh, rv;
-        light_sample_params(g, S.lights[l], rh, rv);
-        fp[VP_DIR + (2 * l + 0) * 64 + lane] = rh, fp[VP_DIR + (2 * l + 1) * 64 + lane] = rv;
-      } else {
-        const f3 tl = light_sample(g, S.lights[l]) - point;
-        fp[VP_DIR + (3 * l + 0) * 64 + lane] = tl.x, fp[VP_DIR + (3 * l + 1) * 64 + lane] = tl.y, fp[VP_DIR + (3 * l + 2) * 64 + lane] = tl.z;
-      }
-    }
-    if (bounce) {
-      const f3 bd = hemisphere_sample<FR>(g, hitNormal);
-      fp[VP::BDIR + lane] = bd.x, fp[VP::BDIR + 64 + lane] = bd.y, fp[VP::BDIR + 128 + lane] = bd.z;
-      keys[lane] = ~0ull;
-    }
-    listB[lanes_below(amask)] = (uint8_t)lane;
-    st.shadow += nl;
-    if (bounce) st.closest++;
-  }
-  if (lane < 2 * POOL_L) res[lane] = 0;
-  const uint32_t kinds = nl + (bounce ? 1u : 0u), R = n * kinds;
-  const uint32_t first = R < 64u ? R : 64u;  // the first hand-out: ranks [0, first) go to this wave's own lanes
-  uint32_t* const D = ctl + CU_DESC + wv * CU_DESC_WORDS;
-  gen = (gen + 1u) & 0x7fffu;
-  // the pool first, then its descriptor, the claim word last, then the mask bit (per-wave DS order)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {
-    __hip_atomic_store(&D[1], R | (n << 9) | (nl << 16) | (bounce ? 1u << 18 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_store(&D[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_store(&D[0], (gen << 16) | first, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (first < R) __hip_atomic_fetch_or(&ctl[CU_AVAIL], 1u << wv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  wave_sync();
-  PH(PH_FILL);
-  uint32_t ownClaimed = first;
-  bool exhausted = first >= R;
-  uint32_t kjw = 0;  // kind | pixel lane << 8 | owner wave << 16 of the ray this lane walks
-  Trav<TRAV_MIXED, LT> T;
-  T.idle(stack, nullptr, 0);
-  T.sharedKey = keys, T.pj = 0;
-  uint32_t* stackBase = stack - lane;
-  bool firstRound = true;
-  bool foreignOpen = false;  // another pool of the workgroup still has rays to hand out (as of the last look)
-  if (!(LT & LT_NOPRIO)) __builtin_amdgcn_s_setprio(1);
-  for (;;) {
-    const uint64_t idle = wave_ballot(!T.live());
-    const int nIdle = __popcll(idle);
-    bool newRay = false, newShared = false;
-    uint32_t newK = 0, newJ = 0, newW = wv;
-    int32_t newNode = 0;
-    if (firstRound) {
-      // every lane is free: rank = lane
-      firstRound = false;
-      if (lane < first) {
-        uint32_t k = (lane >= n) + (lane >= 2 * n) + (lane >= 3 * n);
-        const uint32_t j = listB[lane - k * n];
-        k = bounce ? (k == 0 ? nl : k - 1) : k;  // (the bounce rays, the longest walks, first)
-        newRay = true, newK = k, newJ = j;
-      }
-      PH(PH_HANDOUT);
-    } else if (!exhausted) {
-      if (nIdle >= (int)S.refillT || nIdle == 64) {
-        uint32_t old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(&D[0], (uint32_t)nIdle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old) & 0xffffu;
-        const uint32_t r = old + lanes_below(idle);
-        if (!T.live() && r < R) {
-          uint32_t k = (r >= n) + (r >= 2 * n) + (r >= 3 * n);
-          const uint32_t j = listB[r - k * n];
-          k = bounce ? (k == 0 ? nl : k - 1) : k;
-          newRay = true, newK = k, newJ = j;
-        }
-        const uint32_t hi = old + (uint32_t)nIdle;
-        ownClaimed += (hi < R ? hi : R) - (old < R ? old : R);
-        if (hi >= R) {
-          exhausted = true;
-          if (lane == 0) __hip_atomic_fetch_and(&ctl[CU_AVAIL], ~(1u << wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      PH(PH_HANDOUT);
-    } else {
-      // This pool has nothing left to hand out.  While ANY pool of the workgroup still has, the wave goes
-      // on as in its own hand-out phase — free lanes (>= refillT of them) take fresh rays there —; only
-      // when every pool is drained does it split its own last long rays (in-wave stealing, >= stealT).
-      const bool own = (kjw >> 16) == wv;
-      uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(&ctl[CU_AVAIL])) & ~(1u << wv);
-      if (mask) {
-        // (a wave whose own pool is complete only finishes what it holds and moves on)
-        const bool ownLive = wave_ballot(T.live() && own) != 0;
-        if (!ownLive && lds_load(&D[2]) == R - ownClaimed) mask = 0, foreignOpen = false;
-      }
-      foreignOpen = mask != 0;
-      if (mask) {
-        if (nIdle >= (int)S.refillT || nIdle == 64) {
-          // the next pool after this wave's own, cyclically (waves spread over the victims)
-          const uint32_t rot = (mask >> (wv + 1u)) | (mask << (31u - wv));  // bit b of rot <-> wave (wv + 1 + b) mod 32; waves < 16
-          const uint32_t v = (wv + 1u + (uint32_t)__builtin_ctz(rot)) & 31u;
-          uint32_t* const DV = ctl + CU_DESC + v * CU_DESC_WORDS;
-          const uint32_t hw = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&DV[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-          const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(&DV[1]));
-          const uint32_t Rv = info & 511u, nv = (info >> 9) & 127u, nlv = (info >> 16) & 3u, bv = (info >> 18) & 1u;
-          const uint32_t hv = hw & 0xffffu;
-          if (hv < Rv) {
-            const uint32_t take = (uint32_t)nIdle < Rv - hv ? (uint32_t)nIdle : Rv - hv;
-            uint32_t seen = ~hw;
-            if (lane == 0) {
-              seen = hw;
-              __hip_atomic_compare_exchange_strong(&DV[0], &seen, hw + take, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
-            if (seen == hw) {  // ranks [hv, hv + take) of pool v, generation hw >> 16, are this wave's
-              const uint32_t r = hv + lanes_below(idle);
-              if (!T.live() && r < hv + take) {
-                const uint8_t* listV = listB + (int32_t)(v - wv) * waveWords * 4;
-                uint32_t k = (r >= nv) + (r >= 2 * nv) + (r >= 3 * nv);
-                const uint32_t j = listV[r - k * nv];
-                k = bv ? (k == 0 ? nlv : k - 1) : k;
-                newRay = true, newK = k, newJ = j, newW = v;
-              }
-              if (hv + take >= Rv && lane == 0) __hip_atomic_fetch_and(&ctl[CU_AVAIL], ~(1u << v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          } else if (lane == 0) {
-            __hip_atomic_fetch_and(&ctl[CU_AVAIL], ~(1u << v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a stale bit)
-          }
-        }
-        PH(PH_FOREIGN);
-      } else if (nIdle >= (int)S.stealT) {
-        // split this wave's own long rays (as vertex_pool does; only lanes that walk a ray of THIS pool give:
-        // a ray taken from another wave is walked by exactly one lane, so that "finished" is well defined)
-        uint16_t* list16 = reinterpret_cast<uint16_t*>(list);
-        uint32_t given = 0;
-        const int avail = (T.live() && own) ? T.depth() - T.stolen : 0;
-        int gave = 0;
-        for (int pass = 0; pass < 4; pass++) {
-          const bool canGive = avail > pass;
-          const uint64_t vmask = wave_ballot(canGive);
-          if (vmask == 0 || given >= (uint32_t)nIdle) break;
-          const uint32_t slot = given + lanes_below(vmask);
-          const bool gives = canGive && slot < (uint32_t)nIdle;
-          if (gives) list16[slot] = (uint16_t)(lane | ((uint32_t)(T.stolen + pass) << 6));
-          gave += gives ? 1 : 0;
-          given += (uint32_t)__popcll(vmask);
-        }
-        if (gave) {
-          if (!T.shared && !T.anyHit && T.found) T.publish();
-          T.shared = true;
-          T.stolen += gave;
-        }
-        given = given < (uint32_t)nIdle ? given : (uint32_t)nIdle;
-        if (given != 0) {
-          wave_sync();
-          const uint32_t q = lanes_below(idle);
-          const bool thief = !T.live() && q < given;
-          const uint32_t w = thief ? (uint32_t)list16[q] : lane;
-          const uint32_t v = w & 63u, e = w >> 6;
-          const uint32_t kj = (uint32_t)__shfl((int)kjw, (int)v, 64);  // (all lanes take part)
-          if (thief) {
-            uint32_t* slot = stackBase + (e + 1u) * BLOCK + v;  // (row 0 is the sentinel)
-            newNode = (int32_t)*slot;
-            *slot = (uint32_t)TERM;
-            newRay = true, newShared = true, newK = kj & 255u, newJ = (kj >> 8) & 255u;
-          }
-          wave_sync();
-        }
-        PH(PH_STEAL);
-      }
-    }
-    if (newRay) {
-      const int32_t off = (int32_t)(newW - wv) * waveWords;  // the owner's pool, in words from this wave's
-      const float* fq = fp + off;
-      const f3 pj = mk(fq[VP_PT + newJ], fq[VP_PT + 64 + newJ], fq[VP_PT + 128 + newJ]);
-      f3 dj;
-      if (CP) {
-        if (newK < nl) {
-          const rt_light& Lt = S.lights[newK];
-          const float rh = fq[VP_DIR + (2 * newK + 0) * 64 + newJ], rv = fq[VP_DIR + (2 * newK + 1) * 64 + newJ];
-          dj = light_point(Lt, rh, rv) - pj;
-        } else {
-          dj = mk(fq[VP::BDIR + newJ], fq[VP::BDIR + 64 + newJ], fq[VP::BDIR + 128 + newJ]);
-        }
-      } else {
-        const uint32_t src = newK < nl ? VP_DIR + 192 * newK : VP::BDIR;
-        dj = mk(fq[src + newJ], fq[src + 64 + newJ], fq[src + 128 + newJ]);
-      }
-      T.start(pj, dj, S.invBoxScale);
-      if (T.live()) T.cur = newNode;  // (a NaN ray stays dead)
-      T.anyHit = newK < nl, T.shared = newShared;
-      T.pj = newJ + (uint32_t)(off / 2);  // (index into the OWNER's keys, counted from this wave's)
-      kjw = newK | (newJ << 8) | (newW << 16);
-      // a foreign ray that is dead on arrival is finished
-      if (!T.live() && newW != wv) __hip_atomic_fetch_add(ctl + CU_DESC + newW * CU_DESC_WORDS + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    if (wave_ballot(T.live()) == 0) {
-      // nothing to walk: done when nothing is left to claim and the others have returned their share
-      if (exhausted) {
-        if (lds_load(&D[2]) == R - ownClaimed) break;
-        __builtin_amdgcn_s_sleep(2);
-        PH(PH_FOREIGN);
-      }
-      continue;
-    }
-    const int need = min(64, (exhausted && !foreignOpen) ? (int)S.stealT : (int)S.refillT);
-    for (;;) {
-      const uint32_t myK = kjw & 255u, myJ = (kjw >> 8) & 255u;
-      if (T.shared && T.live()) {  // (shared rays are this pool's own)
-        if (T.anyHit) {
-          if ((res[myK * 2 + (myJ >> 5)] >> (myJ & 31)) & 1u) T.cur = TERM;
-        } else {
-          T.refresh_best();
-        }
-      }
-      const bool was = T.live();
-      PH(PH_POOLMISC);
-      if (exhausted && !foreignOpen) PHC(PH_TAIL);
-      T.template round<STATS>(S, st);
-      if (was && !T.live()) {
-        const uint32_t myW = kjw >> 16;
-        const int32_t off = (int32_t)(myW - wv) * waveWords;
-        if (T.found) {
-          if (myK < nl) atomicOr(res + off + (myK * 2 + (myJ >> 5)), 1u << (myJ & 31));
-          else if (!T.shared) T.publish();  // shared rays publish every improvement as it happens
-        }
-        if (myW != wv) __hip_atomic_fetch_add(ctl + CU_DESC + myW * CU_DESC_WORDS + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (__popcll(wave_ballot(!T.live())) >= need) break;
-    }
-  }
-  if (!(LT & LT_NOPRIO)) __builtin_amdgcn_s_setprio(0);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  wave_sync();
-  PH(PH_POOLMISC);
-  const f3 pt = mk(fp[VP_PT + lane], fp[VP_PT + 64 + lane], fp[VP_PT + 128 + lane]);
-  point = pt;
-  if (bounce) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
-  if (alive) {
-    const BsdfBase base = bsdf_base<FR>(S.mats[mesh], hitNormal, -rayDir);
-    for (uint32_t l = 0; l < nl; l++) {
-      if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
-      const f3 toLight = CP ? light_point(S.lights[l], fp[VP_DIR + (2 * l + 0) * 64 + lane], fp[VP_DIR + (2 * l + 1) * 64 + lane]) - pt
-                            : mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
-      const f3 bsdf = bsdf_apply<FR>(base, toLight);
-      const f3 radiance = light_eval(S.lights[l], pt);
-      color = color + radiance * bsdf;
-    }
-    if (bounce) {
-      const unsigned long long key = keys[lane];
-      nextFound = key != ~0ull;
-      next.t = __uint_as_float((uint32_t)(key >> 32)), next.id = (uint32_t)key;
-      next.u = next.v = 0.f, next.mesh = 0u;
-    }
-  }
-  wave_sync();
-  PH(PH_BSDF);
-  return color;
-}
-
 RT_DEV uint32_t wave_sum(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
@@ -1504,8 +1044,8 @@ RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool 
   const uint32_t c = wave_sum(st.closest), s = wave_sum(st.shadow), q = wave_sum(st.knn);
   uint32_t n = 0, t = 0, kd = 0;
   uint32_t wn = 0, wl = 0;
-  uint32_t lw = 0, li = 0;
-  if (stats) n = wave_sum(st.nodes), t = wave_sum(st.tris), kd = wave_sum(st.kd), wn = wave_sum(st.wnode), wl = wave_sum(st.wleaf), lw = wave_sum(st.lwait), li = wave_sum(st.lidle);
+  uint32_t lw = 0, li = 0, fr = 0;
+  if (stats) fr = wave_sum(st.frames), n = wave_sum(st.nodes), t = wave_sum(st.tris), kd = wave_sum(st.kd), wn = wave_sum(st.wnode), wl = wave_sum(st.wleaf), lw = wave_sum(st.lwait), li = wave_sum(st.lidle);
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&counters[RTK_CNT_CLOSEST], (unsigned long long)c);
     atomicAdd(&counters[RTK_CNT_SHADOW], (unsigned long long)s);
@@ -1518,6 +1058,7 @@ RT_DEV void flush_stats(const LaneStats& st, unsigned long long* counters, bool 
       atomicAdd(&counters[RTK_CNT_WLEAF], (unsigned long long)wl);
       atomicAdd(&counters[RTK_CNT_LWAIT], (unsigned long long)lw);
       atomicAdd(&counters[RTK_CNT_LIDLE], (unsigned long long)li);
+      if (fr) atomicAdd(&counters[RTK_CNT_FRAMES], (unsigned long long)fr);
     }
   }
 }
@@ -1569,16 +1110,10 @@ RT_DEV Lds carve_lds(uint32_t* base, uint32_t levels = STACK, uint32_t kslots = 
 // direct-lighting step exchanges rays between lanes through LDS.
 // One wave tile: lane = (pixel pl of the tile, sample slot sj).  The wave integrates
 // S = 1 << sshift consecutive samples of P = 64 >> sshift pixels side by side.
-struct CuShare {  // CU-level ray sharing (vertex_pool_cus): the workgroup's control block and this wave's place in it
-  uint32_t* ctl = nullptr;
-  uint32_t wv = 0;
-  int32_t waveWords = 0;
-  uint32_t gen = 0;
-};
 
 template <bool BRUTE, bool PHOTON, bool POOLED, bool STATS, int LT>
 RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restrict__ accum, const Lds& L, uint32_t* pool,
-                        float* ex, uint32_t wave, LaneStats& st, CuShare* cu = nullptr) {
+                        float* ex, uint32_t wave, LaneStats& st) {
   constexpr bool FR = (LT & LT_FASTDET) != 0;  // 1 / length by rtd::recip_fast (see rtd::unit3)
   const uint32_t lane = threadIdx.x & 63u;
   // lane = (pixel pl of the wave tile, sample slot sj): the wave integrates
@@ -1608,7 +1143,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
       // primary ray (coherent: traced in lock step), then one pool per vertex
       HitRec h;
       if (alive) st.closest++;
-      const bool hit0 = cast<false, false, STATS, LT & ~LT_CUS>(S, alive, o, d, L.stack, h, st, L.over);
+      const bool hit0 = cast<false, false, STATS, LT>(S, alive, o, d, L.stack, h, st);
       if (alive && !hit0) primary = false, alive = false;
       for (int depth = 0; depth < nvert; depth++) {
         if (wave_ballot(alive) == 0) break;
@@ -1624,12 +1159,7 @@ RT_DEV void render_tile(const DevScene& S, const RenderArgs& A, float4* __restri
         // stream ends there — the pool only draws it when a bounce ray follows)
         HitRec nh;
         bool nfound;
-        f3 c;
-        if constexpr ((LT & LT_CUS) != 0)
-          c = vertex_pool_cus<STATS, LT & ~LT_CUS>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st, cu->ctl, cu->wv,
-                                                   cu->waveWords, cu->gen);
-        else
-          c = vertex_pool<STATS, LT>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st, L.over);
+        const f3 c = vertex_pool<STATS, LT>(S, alive, bounce, g, d, mesh, nrm, pt, bdir, L.stack, pool, nh, nfound, st);
         if (alive) {
           if (depth == 0) c0 = c;
           else if (depth == 1) c1 = c;
@@ -1733,18 +1263,12 @@ __global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs 
     uint4* dst = reinterpret_cast<uint4*>(g_lds);
     for (uint32_t i = threadIdx.x; i < 2u * S.topK; i += blockDim.x) dst[i] = S.nodes[i];
   }
-  // the control block of the CU-level ray sharing: behind the waves' regions
-  uint32_t* const ctl = g_lds + 8u * S.topK + (blockDim.x >> 6) * A.waveWords;
-  if ((LT & LT_CUS) && threadIdx.x < rtbvh::kCtlWords) ctl[threadIdx.x] = 0u;
   __syncthreads();  // the only workgroup-wide barrier
   uint32_t* mine = g_lds + 8u * S.topK + wv * A.waveWords;
   Lds L = carve_lds<false>(mine, A.stackLevels, 0);
-  if (LT & LT_SS) L.over = S.ssOver + ((size_t)blockIdx.x * (blockDim.x >> 6) + wv) * S.ssOvRows * BLOCK + lane;
   uint32_t* pool = mine + A.stackLevels * BLOCK;
   float* ex = reinterpret_cast<float*>(pool);
   LaneStats st;
-  CuShare cu;
-  cu.ctl = ctl, cu.wv = wv, cu.waveWords = (int32_t)A.waveWords;
 #ifdef RT_PHASE_TIMING
   if (threadIdx.x < 24) g_phAcc[threadIdx.x] = 0;
   if (threadIdx.x == 0) g_phT0 = __builtin_amdgcn_s_memtime();
@@ -1755,7 +1279,7 @@ __global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs 
     if (lane == 0) t = atomicAdd(A.tileCounter, 1u);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     if (t >= A.n_tiles) break;
-    render_tile<false, false, true, STATS, LT>(S, A, accum, L, pool, ex, t, st, &cu);
+    render_tile<false, false, true, STATS, LT>(S, A, accum, L, pool, ex, t, st);
   }
 #ifdef RT_PHASE_TIMING
   __syncthreads();
@@ -1886,7 +1410,7 @@ __global__ void k_unpack_owned(const float4* __restrict__ packed, float4* __rest
 template <bool BRUTE, bool ANY, int LT = LT_NONE>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, const rt_ray* __restrict__ rays, uint32_t n,
                                                  rt_hit* __restrict__ hits, unsigned long long* counters) {
-  __shared__ uint32_t lds[(STACK + 3) * BLOCK];  // (+1 sentinel row, +2 rows a wide step writes ahead)
+  __shared__ uint32_t lds[(STACK + 1) * BLOCK];  // (+1: the sentinel row)
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   LaneStats st;
   if (i < n) {
@@ -2110,7 +1634,7 @@ static bool allow_big_lds(K kernel, unsigned long long& done) {
   // (the diagnostic build stays 256 B short of the CU's 160 KiB for its static LDS: the attribute
   // is refused when static + dynamic exceed the CU)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             4 * (rtbvh::kLdsWordsPerCU + rtbvh::kCtlWords));
+                             4 * rtbvh::kLdsWordsPerCU);
   done |= 1ull << dev;
   return true;
 }
@@ -2119,12 +1643,11 @@ static bool allow_big_lds(K kernel, unsigned long long& done) {
 // topK tree-top nodes in front of W private regions of waveWords each.  160 KiB per CU.
 struct PersistPlan {
   uint32_t waves, topK, waveWords, ldsBytes;
-  uint32_t ssRows;  // > 0: short stack (that many entries in LDS, the rest in HBM)
   int compact = 0;  // 1: LT_COMPACT pool layout, 2: LT_COMPACT2
 };
-static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A, bool wide) {
+static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   const uint32_t total = rtbvh::kLdsWordsPerCU;  // words
-  const uint32_t waveWords = (wide ? A.stackLevelsWide : A.stackLevels) * BLOCK + VP_WORDS;
+  const uint32_t waveWords = A.stackLevels * BLOCK + VP_WORDS;
   static const int wEnv = getenv("RT_PERSIST_WAVES") ? atoi(getenv("RT_PERSIST_WAVES")) : 0;
   static const int kEnv = getenv("RT_TOPK") ? atoi(getenv("RT_TOPK")) : -1;
   const uint32_t cap = S.n_nodes < rtbvh::kTopNodes ? S.n_nodes : rtbvh::kTopNodes;
@@ -2132,29 +1655,12 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A, bool wid
   // on every scene; the whole tree in LDS (LT_ALL, no branch) gives C2 +5.6 %.  So: as many
   // waves as fit (at most 16), then as much of the tree as fits beside them.
   // RT_PERSIST_WAVES / RT_TOPK override.
-  PersistPlan best{0, 0, waveWords, 0, 0};
-  // SHORT STACK (RT_SS=1; opt-in): 12 entries per lane in LDS, deeper ones in HBM, so that 16
-  // waves leave room for the top of a deep tree (the most-visited ~1,100 nodes of a 21-level one).
-  // Measured on the 1 M-triangle scene: the spill bookkeeping costs 11 %, the
-  // partial LDS top another 6 % — the full-depth stack (which already fits 16 waves) stays the default.
-  static const int ssEnv = getenv("RT_SS") ? atoi(getenv("RT_SS")) : -1;
-  const bool deep = false;
-  static const int ssRowsEnv = getenv("RT_SS_ROWS") ? atoi(getenv("RT_SS_ROWS")) : 12;  // (tests force it small)
-  const uint32_t ssRowsWanted = ssRowsEnv < 1 ? 1u : (uint32_t)ssRowsEnv;
-  if (!wide && A.ssOver && (ssEnv >= 0 ? ssEnv != 0 : deep) && A.stackLevels - 1u > ssRowsWanted) {
-    const uint32_t rows = ssRowsWanted, ww = (rows + 1u) * BLOCK + VP_WORDS;
-    uint32_t w2 = wEnv > 0 ? (uint32_t)wEnv : 16u;
-    uint32_t k2 = (total - w2 * ww) / 8u;
-    k2 = k2 < cap ? k2 : cap;
-    if (kEnv >= 0) k2 = (uint32_t)kEnv < k2 ? (uint32_t)kEnv : k2;
-    return PersistPlan{w2, k2, ww, 4u * (8u * k2 + w2 * ww), rows};
-  }
   uint32_t w = wEnv > 0 ? (uint32_t)wEnv : 16u;
   while (w > 1u && w * waveWords > total) --w;
-  if (w * waveWords > total) return best;
+  if (w * waveWords > total) return PersistPlan{0, 0, waveWords, 0};
   // big trees whose stacks leave fewer than 16 waves: the compact pool, if it buys a wave
   static const int cpEnv = getenv("RT_COMPACT") ? atoi(getenv("RT_COMPACT")) : -1;
-  if (cpEnv != 0 && (S.n_nodes > kPrioMaxNodes || wide) && w < 16u && (kEnv < 0 || wide)) {
+  if (cpEnv != 0 && (S.n_nodes > kPrioMaxNodes || S.q8) && w < 16u && kEnv < 0) {
     // (the smallest step that buys the most waves; RT_COMPACT = 1 / 2 forces a level)
     uint32_t bestW = w;
     int level = 0;
@@ -2166,21 +1672,19 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A, bool wid
     }
     if (level) {
       const uint32_t ww = waveWords - (uint32_t)(level * VP_COMPACT_SAVES);
-      PersistPlan cp{bestW, 0, ww, 4u * bestW * ww, 0};
+      PersistPlan cp{bestW, 0, ww, 4u * bestW * ww};
       cp.compact = level;
       return cp;
     }
   }
-  if (wide) return PersistPlan{w, 0, waveWords, 4u * w * waveWords, 0};  // (wide records are not copied into LDS)
-  uint32_t k = (total - w * waveWords) / 8u;
+  uint32_t k = S.q8 ? 0u : (total - w * waveWords) / 8u;  // (Q8 records are not copied into LDS)
   k = k < cap ? k : cap;
   // (a PARTIAL top — a prefix of the area-ordered node array — costs the step a second load path;
   // with the step as lean as it is now it pays from a few hundred nodes up: the 11.7 k-triangle
   // mesh keeps 688 of its 6,003 nodes in LDS beside 16 waves, +1.8 %; 256 nodes +0.7 %)
   if (kEnv >= 0) k = (uint32_t)kEnv < k ? (uint32_t)kEnv : k;
   else if (k < S.n_nodes && k < 256u) k = 0;
-  best = PersistPlan{w, k, waveWords, 4u * (8u * k + w * waveWords), 0};
-  return best;
+  return PersistPlan{w, k, waveWords, 4u * (8u * k + w * waveWords)};
 }
 
 template <bool BRUTE, bool PHOTON, bool POOLED>
@@ -2190,95 +1694,41 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   if (blocks == 0) return hipSuccess;
   static const bool noPersist = getenv("RT_NO_PERSIST") != nullptr;
   if (POOLED && !noPersist && A.tileCounter && A.numCUs) {
-    const bool wide = S.nodes4 != nullptr;
-    const PersistPlan P = plan_persist(S, A, wide);
+    const PersistPlan P = plan_persist(S, A);
     if (P.waves) {
       DevScene S2 = S;
       RenderArgs A2 = A;
       S2.topK = P.topK, A2.waveWords = P.waveWords;
-      if (wide) A2.stackLevels = A.stackLevelsWide;
-      if (P.ssRows) {
-        S2.ssRows = P.ssRows, S2.ssOver = A.ssOver, S2.ssOvRows = 32u;
-        A2.stackLevels = P.ssRows + 1u;
-      }
       hipError_t e = hipMemsetAsync(A.tileCounter, 0, sizeof(uint32_t), stream);
       if (e != hipSuccess) return e;
       const uint32_t perCU = P.waves;                                    // waves one workgroup brings
       const uint32_t wgs = (blocks + perCU - 1) / perCU < A.numCUs ? (blocks + perCU - 1) / perCU : A.numCUs;
-#define RT_LAUNCH_PERSIST(ST, LTV)                                                                                      \
-  do {                                                                                                                  \
-    static unsigned long long done = 0;                                                                                 \
-    if (!allow_big_lds(&k_render_persist<ST, LTV>, done)) return hipErrorInvalidConfiguration;                          \
-    hipLaunchKernelGGL((k_render_persist<ST, LTV>), dim3(wgs), dim3(64u * P.waves), P.ldsBytes + 4u * rtbvh::kCtlWords, \
-                       stream, S2, A2, accum, counters);                                                                \
+#define RT_LAUNCH_PERSIST(ST, LTV)                                                                          \
+  do {                                                                                                      \
+    static unsigned long long done = 0;                                                                     \
+    if (!allow_big_lds(&k_render_persist<ST, LTV>, done)) return hipErrorInvalidConfiguration;              \
+    hipLaunchKernelGGL((k_render_persist<ST, LTV>), dim3(wgs), dim3(64u * P.waves), P.ldsBytes, stream, S2, \
+                       A2, accum, counters);                                                                \
   } while (0)
-      // the timed (uncounted) default instances: with the three-instruction 1 / det where the host has bounded |det|
-#define RT_LAUNCH_FAST(LTV)                                       \
-  do {                                                            \
-    if (S.slowRecip) RT_LAUNCH_PERSIST(false, LTV);               \
-    else RT_LAUNCH_PERSIST(false, (LTV) | LT_FASTDET);            \
+      // Two instances per layout: the timed one, with the three-instruction 1 / det and 1 / length (the host has bounded
+      // their operands: DevScene::slowRecip == 0), and the COUNTED one, which divides — and which also serves the rare
+      // scene beyond those bounds (same frame: the short forms give the division's bits).
+#define RT_LAUNCH_EITHER(LTV)                                    \
+  do {                                                           \
+    if (stats || S.slowRecip) RT_LAUNCH_PERSIST(true, LTV);      \
+    else RT_LAUNCH_PERSIST(false, (LTV) | LT_FASTDET);           \
   } while (0)
-      // CU-level ray sharing (vertex_pool_cus): OPT-IN, RT_CUSHARE=1.  Built, bit-exact and measured:
-      // C2 66.2 vs 50.8 ms, lanes per node step 29.4 vs 36.4 — sharing balances the 16 pools of a CU, so they drain
-      // together and the tail becomes CU-wide; what bounds a pool is the dependency chain of its samples (one
-      // longest ray per path depth), not the spread between waves.
-      static const bool cuShare = getenv("RT_CUSHARE") && atoi(getenv("RT_CUSHARE")) != 0;
-      const bool cus = cuShare && P.waves > 1u;
       const int lt = P.topK == 0 ? LT_NONE : P.topK >= S.n_nodes ? LT_ALL : LT_TOP;
-      if (wide) {
-        if (P.compact == 2) {
-          if (stats) RT_LAUNCH_PERSIST(true, LT_WIDE | LT_NOPRIO | LT_COMPACT2);
-          else RT_LAUNCH_PERSIST(false, LT_WIDE | LT_NOPRIO | LT_COMPACT2);
-        } else if (P.compact) {
-          if (stats) RT_LAUNCH_PERSIST(true, LT_WIDE | LT_NOPRIO | LT_COMPACT);
-          else RT_LAUNCH_PERSIST(false, LT_WIDE | LT_NOPRIO | LT_COMPACT);
-        } else {
-          if (stats) RT_LAUNCH_PERSIST(true, LT_WIDE | LT_NOPRIO);
-          else RT_LAUNCH_PERSIST(false, LT_WIDE | LT_NOPRIO);
-        }
-      } else if (P.compact == 2) {
-        if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT2);
-        else RT_LAUNCH_FAST(LT_NONE | LT_NOPRIO | LT_COMPACT2);
-      } else if (P.compact) {
-        if (cus) {
-          if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT | LT_CUS);
-          else RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_COMPACT | LT_CUS);
-        } else {
-          if (stats) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_COMPACT);
-          else RT_LAUNCH_FAST(LT_NONE | LT_NOPRIO | LT_COMPACT);
-        }
-      } else if (P.ssRows) {
-        if (stats) {
-          if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP | LT_SS);
-          else RT_LAUNCH_PERSIST(true, LT_NONE | LT_SS);
-        } else {
-          if (lt == LT_TOP) RT_LAUNCH_PERSIST(false, LT_TOP | LT_SS);
-          else RT_LAUNCH_PERSIST(false, LT_NONE | LT_SS);
-        }
-      } else if (cus) {
-        if (stats) {
-          if (lt == LT_ALL) RT_LAUNCH_PERSIST(true, LT_ALL | LT_CUS);
-          else if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP | LT_CUS);
-          else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO | LT_CUS);
-          else RT_LAUNCH_PERSIST(true, LT_NONE | LT_CUS);
-        } else {
-          if (lt == LT_ALL) RT_LAUNCH_PERSIST(false, LT_ALL | LT_CUS);
-          else if (lt == LT_TOP) RT_LAUNCH_PERSIST(false, LT_TOP | LT_CUS);
-          else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_PERSIST(false, LT_NONE | LT_NOPRIO | LT_CUS);
-          else RT_LAUNCH_PERSIST(false, LT_NONE | LT_CUS);
-        }
-      } else if (stats) {
-        if (lt == LT_ALL) RT_LAUNCH_PERSIST(true, LT_ALL);
-        else if (lt == LT_TOP) RT_LAUNCH_PERSIST(true, LT_TOP);
-        else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_PERSIST(true, LT_NONE | LT_NOPRIO);
-        else RT_LAUNCH_PERSIST(true, LT_NONE);
-      } else {
-        if (lt == LT_ALL) RT_LAUNCH_FAST(LT_ALL);
-        else if (lt == LT_TOP) RT_LAUNCH_FAST(LT_TOP);
-        else if (S.n_nodes > kPrioMaxNodes) RT_LAUNCH_FAST(LT_NONE | LT_NOPRIO);
-        else RT_LAUNCH_FAST(LT_NONE);
-      }
-#undef RT_LAUNCH_FAST
+      if (S.q8) {  // the one-request records (the context chose them: rt_api.cpp create_ctx)
+        if (P.compact == 2) RT_LAUNCH_EITHER(LT_Q8 | LT_NOPRIO | LT_COMPACT2);
+        else if (P.compact) RT_LAUNCH_EITHER(LT_Q8 | LT_NOPRIO | LT_COMPACT);
+        else RT_LAUNCH_EITHER(LT_Q8 | LT_NOPRIO);
+      } else if (P.compact == 2) RT_LAUNCH_EITHER(LT_NONE | LT_NOPRIO | LT_COMPACT2);
+      else if (P.compact) RT_LAUNCH_EITHER(LT_NONE | LT_NOPRIO | LT_COMPACT);
+      else if (lt == LT_ALL) RT_LAUNCH_EITHER(LT_ALL);
+      else if (lt == LT_TOP) RT_LAUNCH_EITHER(LT_TOP);
+      else RT_LAUNCH_EITHER(LT_NONE | LT_NOPRIO);  // (a small tree beside stacks that leave no room for 256 of its nodes: rare)
+#undef RT_LAUNCH_EITHER
 #undef RT_LAUNCH_PERSIST
       return hipGetLastError();
     }
@@ -2359,42 +1809,6 @@ hipError_t launch_pack(bool unpack, const float4* src, float4* dst, const uint32
   return hipGetLastError();
 }
 
-// ray mode + photon map (BASELINE config 3): primary cast, vertex, the k-NN query stream, the radiance estimate
-hipError_t launch_wavefront_photon(const DevScene& S, const WfArgs& W0, uint32_t k, uint32_t photonsRequested, float4* accum,
-                                   unsigned long long* counters, uint32_t* queueCounter, uint32_t numCUs, hipStream_t stream) {
-  const uint32_t perSample = W0.nGran * 64u;
-  if (perSample == 0 || W0.s1 <= W0.s0) return hipSuccess;
-  uint32_t levels = 1;
-  while ((1ull << levels) <= S.n_photons) ++levels;
-  levels += 1u;
-  const uint32_t waveWords = (2u * k + levels) * BLOCK;
-  uint32_t wpw = 16u;
-  while (wpw > 1u && wpw * waveWords > 160u * 1024u / 4u - 64u) --wpw;
-  const uint32_t ldsBytes = 4u * wpw * waveWords;
-  static unsigned long long done = 0;
-  if (!allow_big_lds(&k_knn_stream, done)) return hipErrorInvalidConfiguration;
-  for (uint32_t s = W0.s0; s < W0.s1; s += W0.batch) {
-    WfArgs W = W0;
-    W.s0 = s;
-    const uint32_t nb = W0.s1 - s < W0.batch ? W0.s1 - s : W0.batch;
-    W.nPaths = nb * perSample;
-    const dim3 blk(256), grd((W.nPaths + 255) / 256);
-    hipLaunchKernelGGL(wf_generate, dim3((W.nPaths + 63) / 64), dim3(64), 0, stream, S, W, counters);
-    hipLaunchKernelGGL(wf_ph_vertex, grd, blk, 0, stream, S, W);
-    hipError_t e = hipMemsetAsync(queueCounter, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    const uint32_t waves = (W.nPaths + 63u) / 64u;
-    uint32_t wgs = (waves + wpw - 1u) / wpw;
-    wgs = wgs < numCUs ? wgs : numCUs;
-    hipLaunchKernelGGL(k_knn_stream, dim3(wgs), dim3(64u * wpw), ldsBytes, stream, S, W.pnt, W.key, W.nPaths, k, levels, W.knn,
-                       queueCounter, counters);
-    hipLaunchKernelGGL(wf_ph_finish, grd, blk, 0, stream, S, W, 0u, k, photonsRequested);
-    hipLaunchKernelGGL(wf_accumulate, dim3((perSample + 255) / 256), blk, 0, stream, W, accum);
-  }
-  hipLaunchKernelGGL(wf_sum_stripes, dim3(1), dim3(1024), 0, stream, W0.stripes, counters);
-  return hipGetLastError();
-}
-
 
 hipError_t launch_trace(bool brute_force, bool any, const DevScene& S, const rt_ray* rays, uint32_t n,
                         rt_hit* hits, unsigned long long* counters, hipStream_t stream) {
@@ -2403,9 +1817,9 @@ hipError_t launch_trace(bool brute_force, bool any, const DevScene& S, const rt_
   if (brute_force) {
     if (any) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, S, rays, n, hits, counters);
     else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, stream, S, rays, n, hits, counters);
-  } else if (S.nodes4) {  // the context traverses the wide form of its tree
-    if (any) hipLaunchKernelGGL((k_trace<false, true, LT_WIDE>), grid, block, 0, stream, S, rays, n, hits, counters);
-    else hipLaunchKernelGGL((k_trace<false, false, LT_WIDE>), grid, block, 0, stream, S, rays, n, hits, counters);
+  } else if (S.q8) {  // the context traverses the one-request records
+    if (any) hipLaunchKernelGGL((k_trace<false, true, LT_Q8>), grid, block, 0, stream, S, rays, n, hits, counters);
+    else hipLaunchKernelGGL((k_trace<false, false, LT_Q8>), grid, block, 0, stream, S, rays, n, hits, counters);
   } else {
     if (any) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, stream, S, rays, n, hits, counters);
     else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, stream, S, rays, n, hits, counters);

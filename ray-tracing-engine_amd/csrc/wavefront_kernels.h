@@ -192,107 +192,6 @@ __global__ void wf_accumulate(WfArgs W, float4* __restrict__ accum) {
   accum[pix] = sum;
 }
 
-// ---------------------------------------------------------------- photon-map shading as a query stream
-// Renderer.cpp:63-104 per primary hit: kdtree::knearest + the radiance estimate.  In the fused kernel a wave runs 64
-// queries side by side until the LONGEST of them is done (109 kd nodes per query on average on C3, about 190 for the
-// slowest of 64: 58 % of the lanes useful).  Here the queries of a batch of paths sit in HBM (W.pnt / W.key), and
-// persistent waves draw them from a counter: a lane whose walk is over stores its result and takes the next query —
-// as soon as enough lanes are free to make the heap set-up of the newcomers worth a wave's time — while its neighbours
-// keep walking.  Same walk (KnnWalk), same heap, same order of the k results, so the same bits.
-//   W.knn[i] = {sum of the k photons' directions in result order (Renderer.cpp:90-95), distance of the k-th one}
-constexpr int KNN_REFILL = 20;  // free lanes that trigger a refill (a refill costs the k-photon heap set-up)
-
-__global__ void wf_ph_vertex(DevScene S, WfArgs W) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= W.nPaths) return;
-  const uint2 key = W.key[i];
-  if (key.y == DEAD) return;
-  const float4 o4 = W.org[i], d4 = W.dir[i];
-  f3 nrm, pt;
-  uint32_t mesh;
-  vertex_setup_ray(S, key.y, mk(o4.x, o4.y, o4.z), mk(d4.x, d4.y, d4.z), nrm, pt, mesh);
-  W.nrm[i] = make_float4(nrm.x, nrm.y, nrm.z, __uint_as_float(mesh));
-  W.pnt[i] = make_float4(pt.x, pt.y, pt.z, 0.f);
-}
-
-__global__ __launch_bounds__(1024) void k_knn_stream(DevScene S, const float4* __restrict__ pnt, const uint2* __restrict__ key,
-                                                     uint32_t n, uint32_t k, uint32_t levels, float4* __restrict__ out,
-                                                     uint32_t* __restrict__ counter, unsigned long long* __restrict__ counters) {
-  extern __shared__ uint32_t knn_lds[];  // per wave: heap [k][64] x 8 B, split distances [levels][64] x 4 B
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  uint32_t* mine = knn_lds + wv * (2u * k + levels) * BLOCK;
-  const Heap H{reinterpret_cast<uint2*>(mine) + lane};
-  float* dxs = reinterpret_cast<float*>(mine + 2u * k * BLOCK) + lane;
-  KnnWalk Wk;
-  // a lane is WALKING, or it holds a finished walk whose result is still in its heap (`done`), or it is free.  Results
-  // are written and new queries set up only at a hand-out, for all waiting lanes at once: the epilogue of a walk (sort
-  // the heap, sum the directions) and the prologue of the next (k distances, make_heap) are a few hundred instructions
-  // that a wave should not issue for one lane at a time.
-  bool walking = false, done = false, drained = false;
-  uint32_t qi = 0, nq = 0;
-  for (;;) {
-    const uint64_t idle = wave_ballot(!walking);
-    const int nIdle = __popcll(idle);
-    if (nIdle >= KNN_REFILL || nIdle == 64) {
-      if (done) {
-        H.sort((int)k);
-        // Renderer.cpp:85-95 on the sorted result: the radius, and the directions summed in result order
-        const float4 far = S.phPos[H.I((int)k - 1)];
-        const float r = dist3(mk(far.x, far.y, far.z), Wk.p);
-        f3 avg = mk(0.f, 0.f, 0.f);
-        for (uint32_t j = 0; j < k; j++) avg = avg + f4xyz(S.phDir[H.I((int)j)]);
-        out[qi] = make_float4(avg.x, avg.y, avg.z, r);
-        done = false;
-      }
-      if (!drained) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(counter, (uint32_t)nIdle);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        drained = base + (uint32_t)nIdle >= n;  // (wave-uniform: nothing behind this hand-out)
-        if (!walking) {
-          const uint32_t i = base + lanes_below(idle);
-          if (i < n && key[i].y != DEAD) {
-            const float4 p4 = pnt[i];
-            qi = i;
-            Wk.init(S, mk(p4.x, p4.y, p4.z), (int)k, H);
-            walking = true, ++nq;
-          }
-        }
-      }
-    }
-    if (wave_ballot(walking) == 0) {
-      if (drained) break;  // (every result has been written: the branch above ran with nIdle == 64)
-      continue;            // (a hand-out of paths that all missed the scene)
-    }
-    if (walking && !Wk.step(S, (int)k, H, dxs)) walking = false, done = true;
-  }
-  const uint32_t q = wsum(nq);
-  if (lane == 0 && q) atomicAdd(&counters[RTK_CNT_KNN], (unsigned long long)q);
-}
-
-__global__ void wf_ph_finish(DevScene S, WfArgs W, uint32_t depth, uint32_t k, uint32_t photonsRequested) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= W.nPaths) return;
-  const uint2 key = W.key[i];
-  if (key.y == DEAD) return;
-  const float4 d4 = W.dir[i], n4 = W.nrm[i], q4 = W.knn[i];
-  const f3 rayDir = mk(d4.x, d4.y, d4.z), nrm = mk(n4.x, n4.y, n4.z);
-  const rt_material mat = S.mats[__float_as_uint(n4.w)];
-  // Renderer.cpp:85-103 (as rt_kernels.hip shade_photon: the same operations in the same order)
-  const float r = q4.w;
-  const float area = (float)(3.14159265358979323846 * (double)r * (double)r);
-  f3 radiance = mk(0.f, 0.f, 0.f);
-  for (uint32_t j = 0; j < k; j++) radiance = radiance + mk(1.f, 1.f, 1.f);
-  radiance = radiance / area;
-  radiance = radiance / (float)(int)photonsRequested;
-  radiance = radiance * 100.f;  // Renderer.h:45
-  const f3 bsdf = bsdf_eval(mat, nrm, unit3(mk(q4.x, q4.y, q4.z)), -rayDir);
-  const f3 color = mk(0.f, 0.f, 0.f) + radiance * bsdf;
-  float4& c = W.col[(size_t)depth * W.nPaths + i];
-  c.x = color.x, c.y = color.y, c.z = color.z;
-  W.key[i] = make_uint2(DEAD, DEAD);  // ray mode: the path ends at its first vertex (Renderer.cpp:106-123)
-}
-
 hipError_t launch_trace_stream(const DevScene& S, const float4* rayO, const float4* rayD, uint32_t n, uint2* res,
                                uint32_t* counter, uint32_t stackLevels, uint32_t numCUs, hipStream_t stream);
 

@@ -56,7 +56,7 @@ class SceneDesc(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("device", C.c_int32), ("bvh_leaf_max", C.c_uint32), ("bvh_builder", C.c_uint32), ("bvh_width", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+    _fields_ = [("device", C.c_int32), ("bvh_leaf_max", C.c_uint32), ("bvh_builder", C.c_uint32), ("node_format", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class Params(C.Structure):
@@ -69,7 +69,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("knn_queries", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("kd_visited", C.c_uint64), ("kernel_ms", C.c_double), ("reserved", C.c_uint64 * 4)]
+                ("kd_visited", C.c_uint64), ("frame_fetches", C.c_uint64), ("kernel_ms", C.c_double), ("reserved", C.c_uint64 * 4)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -83,7 +83,7 @@ class TuneReport(C.Structure):
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_tri_records", C.c_uint32), ("max_depth", C.c_uint32),
                 ("leaf_max", C.c_uint32), ("pad", C.c_float), ("build_ms", C.c_float), ("builder", C.c_uint32),
-                ("n_wide_nodes", C.c_uint32)]
+                ("node_format", C.c_uint32)]
 
 
 RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3)])
@@ -93,7 +93,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("mesh", "<u4"), ("tri", "<u4"), ("vtx", "
 # every symbol include/rt_amd.h / include/rt_host.h declares
 AMD_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_photons", "rt_emit_photons",
                "rt_render", "rt_render_passes", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
-               "rt_bvh_export", "rt_bvh_build_host", "rt_bvh_wide_check_host", "rt_bvh_tune", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
+               "rt_bvh_export", "rt_bvh_build_host", "rt_bvh_check_host", "rt_bvh_tune", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
                "rt_trace_stream_device", "rt_build_photon_map", "rt_get_photons", "rt_test_kd_order", "rt_owned_granules", "rt_pack_owned_device", "rt_unpack_owned_device", "rt_group_create", "rt_group_destroy",
                "rt_group_size", "rt_group_uses_rccl", "rt_group_ctx", "rt_group_set_photons", "rt_group_render"]
 HOST_SYMBOLS = ["rt_host_scene_build", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error",
@@ -144,7 +144,7 @@ def amd():
         L.rt_bvh_tune.argtypes = [C.c_void_p, C.POINTER(Params), C.c_double, C.c_uint32, C.POINTER(TuneReport)]
         L.rt_bvh_build_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.POINTER(BvhInfo),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
-        L.rt_bvh_wide_check_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rt_bvh_check_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rt_profile_reset.argtypes = [C.c_void_p]
         L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.rt_test_unit.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -253,13 +253,17 @@ def bvh_build_host(scene, leaf_max=0, threads=0):
     return info, dig.value, sec.value
 
 
-def bvh_wide_check_host(scene, leaf_max=0, stack_budget=0):
-    """Host build + 4-wide collapse + structural check (no GPU).  Returns a dict of the shape numbers."""
+NODES_AUTO, NODES_F16, NODES_Q8 = 0, 1, 2
+
+
+def bvh_check_host(scene, leaf_max=0, node_format=NODES_F16):
+    """Host build + packing into the given device node format + structural check (no GPU).  Returns a dict of the
+    shape numbers; raises RtError when the packed tree is not a valid tree over the scene's triangles."""
     out = np.zeros(8, np.uint32)
     est = np.zeros(2, np.float64)
-    _check(amd().rt_bvh_wide_check_host(C.byref(scene.desc), leaf_max, stack_budget, _ptr(out), _ptr(est)))
-    return dict(binary_nodes=int(out[0]), wide_nodes=int(out[1]), stack_need=int(out[2]), binary_depth=int(out[3]),
-                k4=int(out[4]), k3=int(out[5]), k2=int(out[6]), visits2=float(est[0]), visits4=float(est[1]))
+    _check(amd().rt_bvh_check_host(C.byref(scene.desc), leaf_max, node_format, _ptr(out), _ptr(est)))
+    return dict(nodes=int(out[0]), slots=int(out[1]), blocks=int(out[2]), depth=int(out[3]), added_nodes=int(out[4]),
+                visits_float=float(est[0]), visits_packed=float(est[1]))
 
 
 def kd_order(pos, dir_, weight=None):
@@ -276,10 +280,10 @@ def kd_order(pos, dir_, weight=None):
 class Context:
     """rt_ctx: the scene resident in HBM on one gfx950 device."""
 
-    def __init__(self, scene, device=0, bvh_leaf_max=0, bvh_builder=0, bvh_width=0):
+    def __init__(self, scene, device=0, bvh_leaf_max=0, bvh_builder=0, node_format=0):
         self.scene = scene
         opt = Options()
-        opt.device, opt.bvh_leaf_max, opt.bvh_builder, opt.bvh_width = device, bvh_leaf_max, bvh_builder, bvh_width
+        opt.device, opt.bvh_leaf_max, opt.bvh_builder, opt.node_format = device, bvh_leaf_max, bvh_builder, node_format
         h = C.c_void_p()
         _check(amd().rt_create(scene.desc_ptr, C.byref(opt), C.byref(h)))
         self._h = h
@@ -425,10 +429,10 @@ def owned_granules(params, rank):
 class Group:
     """rt_group: one process driving N devices (RCCL / peer copies inside librt_amd.so)."""
 
-    def __init__(self, scene, devices, bvh_leaf_max=0, bvh_width=0):
+    def __init__(self, scene, devices, bvh_leaf_max=0, node_format=0):
         self.scene = scene
         opt = Options()
-        opt.bvh_leaf_max, opt.bvh_width = bvh_leaf_max, bvh_width
+        opt.bvh_leaf_max, opt.node_format = bvh_leaf_max, node_format
         devs = (C.c_int32 * len(devices))(*devices)
         h = C.c_void_p()
         _check(amd().rt_group_create(scene.desc_ptr, devs, len(devices), C.byref(opt), C.byref(h)))

@@ -22,7 +22,7 @@ def test_amd_symbols_match_header():
     L = pyrt.amd()
     for s in decl:
         assert hasattr(L, s), s
-    assert L.rt_abi_version() == 1
+    assert L.rt_abi_version() == 2
 
 
 def test_host_symbols_match_header():
@@ -35,7 +35,7 @@ def test_host_symbols_match_header():
 
 def test_struct_sizes():
     assert C.sizeof(pyrt.Material) == 32 and C.sizeof(pyrt.Light) == 84 and C.sizeof(pyrt.Camera) == 48
-    assert C.sizeof(pyrt.Params) == 96 and C.sizeof(pyrt.Stats) == 96
+    assert C.sizeof(pyrt.Params) == 96 and C.sizeof(pyrt.Stats) == 104
     assert pyrt.RAY_DTYPE.itemsize == 24 and pyrt.HIT_DTYPE.itemsize == 36
 
 

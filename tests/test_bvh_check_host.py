@@ -1,0 +1,67 @@
+"""The host-built BVH in its device node formats, checked without a GPU: rt_bvh_check_host builds, packs and
+verifies the structure itself (every node and every triangle record reachable exactly once, every stored child
+box containing its padded geometry, the depth as reported and within the cap)."""
+import numpy as np
+import pytest
+
+import pyrt
+
+FORMATS = [pyrt.NODES_F16, pyrt.NODES_Q8]
+
+
+@pytest.mark.parametrize("kind", ["cubes", "lowres", "hires"])
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_packed_tree_is_a_valid_tree(kind, fmt):
+    s = pyrt.Scene(kind, 32, 32)
+    r = pyrt.bvh_check_host(s, 0, fmt)
+    assert r["nodes"] >= 1 and r["depth"] >= 1
+    # the packed boxes contain the float boxes, so the surface-area estimate of node visits can only grow — and the
+    # encodings are fine enough that it grows by little
+    assert r["visits_float"] <= r["visits_packed"] <= 1.25 * r["visits_float"]
+    if fmt == pyrt.NODES_Q8:
+        assert r["slots"] >= r["nodes"] + r["added_nodes"] and r["blocks"] >= 1
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_leaf_sizes_and_tiny_scenes(fmt):
+    for leaf in (1, 2, 4, 8):
+        if fmt == pyrt.NODES_Q8 and leaf > 2:
+            with pytest.raises(pyrt.RtError):  # the 16-byte record has one count bit per child
+                pyrt.bvh_check_host(pyrt.Scene("lowres", 32, 32), leaf, fmt)
+            continue
+        r = pyrt.bvh_check_host(pyrt.Scene("lowres", 32, 32), leaf, fmt)
+        assert r["nodes"] >= 1
+    # a scene of one, two and three triangles: the root still has two (leaf) children
+    a = pyrt.Scene("cubes", 32, 32).arrays()
+    for ntri in (1, 2, 3):
+        tri = a["tri"][:ntri]
+        sc = pyrt.ArrayScene(a["pos"], a["nrm"], tri, np.array([0, ntri], np.uint32), np.array([0, len(a["pos"])], np.uint32),
+                             a["materials"][:1], a["lights"], a["camera"])
+        r = pyrt.bvh_check_host(sc, 0, fmt)
+        assert r["nodes"] >= 1 and r["depth"] >= 1
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_big_lattice_scene_packs_and_checks(fmt):
+    """The 1 M-triangle stress scene (BASELINE config 5) is what the Q8 format is for: thousands of 16-KiB blocks."""
+    r = pyrt.bvh_check_host(pyrt.Scene("stress", 32, 32), 0, fmt)
+    assert r["nodes"] > 400000
+    if fmt == pyrt.NODES_Q8:
+        assert r["blocks"] > 1000 and r["visits_packed"] <= 1.15 * r["visits_float"]
+
+
+@pytest.mark.parametrize("kind", ["cubes", "lowres"])
+def test_tuner_machinery_on_a_host_computable_cost(kind, monkeypatch):
+    """bvh_build.cpp tuneMeasured (what rt_bvh_tune drives with a probe frame's counters) run on a cost the host can
+    compute, the summed surface area of the child boxes (RT_BVH_TUNE_AREA=probes): proposals, undo of rejected moves,
+    slot flips and the depth bound all run without a GPU, and the structure check must still pass — every triangle once,
+    boxes containing their padded geometry, no leaf deeper than before."""
+    s = pyrt.Scene(kind, 32, 32)
+    monkeypatch.setenv("RT_BVH_ROT", "0")
+    base = pyrt.bvh_check_host(s, 0, pyrt.NODES_F16)
+    monkeypatch.setenv("RT_BVH_TUNE_AREA", "400")
+    tuned = pyrt.bvh_check_host(s, 0, pyrt.NODES_F16)
+    assert tuned["nodes"] == base["nodes"] and tuned["depth"] <= base["depth"]
+    assert tuned["visits_float"] <= base["visits_float"]
+    if kind == "lowres":
+        assert tuned["visits_float"] < 0.995 * base["visits_float"]

@@ -121,12 +121,11 @@ np.savez(sys.argv[2], **out)
     runs = {}
     for name, env in (("default", {}), ("morton_all_the_way", {"RT_BVH_GPU_SUB": "0"}), ("subtrees_64", {"RT_BVH_GPU_SUB": "64"}),
                       ("binned_top", {"RT_BVH_GPU_TOP": "binned"}), ("binned_top_64_bins", {"RT_BVH_GPU_TOP": "binned", "RT_BVH_GPU_BINS": "64"}),
-                      # ... and the host builder's: its default, without the size axis, with an unbiased size axis, with
-                      # reinsertion passes (with and without the rotations behind them)
+                      # ... and the host builder's: its default, without the size axis, with an unbiased size axis,
+                      # without the rotation passes
                       ("host", {"RT_TEST_HOST_BUILDER": "1"}), ("host_no_size_axis", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_SIZEAXIS": "0"}),
                       ("host_size_axis_unbiased", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_SIZEBIAS": "1"}),
-                      ("host_reinsertion", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_REINSERT": "3"}),
-                      ("host_reinsertion_no_rotations", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_REINSERT": "3", "RT_BVH_ROT": "0"})):
+                      ("host_no_rotations", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_ROT": "0"})):
         out = tmp_path / (name + ".npz")
         r = subprocess.run([sys.executable, str(script), pyrt.ROOT, str(out)], env=dict(os.environ, **env), capture_output=True,
                            text=True, timeout=600)

@@ -417,44 +417,6 @@ def test_photon_frame_bit_exact_vs_oracle(kind, w, h, spp, mode, nph, k):
     ctx.close()
 
 
-def test_photon_query_stream_option_is_exact(tmp_path):
-    """RT_PHOTON_STREAM=1 (opt-in, read once per process): photon-map shading in ray mode as a query stream — primary cast,
-    vertex, k_knn_stream (persistent waves whose lanes take the next k-NN query when their walk is over), radiance estimate,
-    ordered accumulation.  The frame and the counts must be the fused kernel's, bit for bit (it is 2 x slower: DESIGN.md 4.6)."""
-    import subprocess
-    import sys
-    script = tmp_path / "ps.py"
-    script.write_text('''
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1] + "/ray-tracing-engine_amd")
-import pyrt
-out = {}
-for kind, w, spp, nph, k in (("cubes", 64, 3, 5000, 10), ("lowres", 40, 5, 4000, 7), ("lowres", 33, 2, 3000, 1)):
-    s = pyrt.Scene(kind, w, w); ctx = pyrt.Context(s)
-    ctx.build_photon_map(nph, seed=4)
-    for world in (1, 2):
-        acc = None
-        for rank in range(world):
-            p = pyrt.make_params(w, w, spp, mode=pyrt.MODE_RAY, seed=9, use_photons=1, k=k, photons_requested=nph, rank=rank, world=world)
-            _, a, st = ctx.render(p)
-            acc = a if acc is None else acc + a
-            out["%s_%d_%d_%d_n" % (kind, k, world, rank)] = np.array([st.rays_closest, st.knn_queries])
-        out["%s_%d_%d" % (kind, k, world)] = acc
-    ctx.close()
-np.savez(sys.argv[2], **out)
-''')
-    runs = {}
-    for name, env in (("fused", {}), ("stream", {"RT_PHOTON_STREAM": "1"})):
-        o = tmp_path / (name + ".npz")
-        r = subprocess.run([sys.executable, str(script), pyrt.ROOT, str(o)], env=dict(os.environ, **env), capture_output=True, text=True,
-                           timeout=300)
-        assert r.returncode == 0, (name, r.stderr[-2000:])
-        runs[name] = np.load(o)
-    for key in runs["fused"].files:
-        a, b = runs["fused"][key], runs["stream"][key]
-        assert np.array_equal(bits(a) if a.dtype == np.float32 else a, bits(b) if b.dtype == np.float32 else b), key
-
-
 @pytest.mark.parametrize("kind,n", [("hires", 300000), ("stress", 4000)])
 def test_bvh_equals_exhaustive_loop_on_big_scenes(kind, n):
     """11.7k-triangle and 1M-triangle scenes: every field of every hit record from the
