@@ -875,7 +875,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
     // point per iteration (two start sites cost ~25 register copies per round)
     bool newRay = false, newShared = false;
     uint32_t newK = 0, newJ = 0;
-    int32_t newNode = 0;
+    int32_t newNode = (LT & LT_Q8) ? (int32_t)rtbvh::kQ8RootOffset : 0;  // (the root's record)
     f3 dv = mk(0.f, 0.f, 0.f);  // (CP2) direction of the ray a thief joins, from the victim's registers
     if (CP2 && bounce && head == 0) {
       // first hand-out (every lane is free): each bounce ray to its own pixel lane, the first
