@@ -318,6 +318,40 @@ __global__ void k_photon_gather(const float4* __restrict__ items, const float4* 
   if (perm) perm[i] = src;
 }
 
+// The tree's EXPLICIT topology, for the k-NN walk (rt_kernels.hip knn_query).  The reference's tree is implicit in the
+// array order (kdtree.h:60-69: the node of a range [b, e) is its median element b + (e - b) / 2, the halves are its
+// children, the axis cycles with the depth), and a walk that carries (b, e, depth) spends a third of its instructions on
+// range and level arithmetic.  One record per photon instead: {left child | axis << 30, right child, the PARENT's split
+// coordinate (float bits), the parent's axis}; no child = KD_NONE.  The parent's split lets a far child that waited on
+// the walk's stack be re-tested against kdtree.h:105 (dx * dx >= m_bestdist) from its own record when it is popped.
+__global__ void k_kd_topology(const float4* __restrict__ phPos, uint32_t n, uint4* __restrict__ topo) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t b = 0, e = n, level = 0, parent = 0x3fffffffu;
+  for (;;) {
+    const uint32_t m = b + (e - b) / 2;
+    if (m == i) break;
+    parent = m;
+    if (i < m) e = m;
+    else b = m + 1;
+    ++level;
+  }
+  const uint32_t left = i > b ? b + (i - b) / 2 : 0x3fffffffu, right = e > i + 1 ? (i + 1) + (e - i - 1) / 2 : 0x3fffffffu;
+  uint32_t psplit = 0, paxis = 0;
+  if (parent != 0x3fffffffu) {
+    paxis = (level - 1) % 3;
+    const float4 pp = phPos[parent];
+    psplit = __float_as_uint(paxis == 0 ? pp.x : paxis == 1 ? pp.y : pp.z);
+  }
+  topo[i] = make_uint4(left | ((level % 3) << 30), right, psplit, paxis);
+}
+
+hipError_t launch_kd_topology(const float4* phPos, uint32_t n, uint4* topo, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_kd_topology, dim3((n + 255) / 256), dim3(256), 0, stream, phPos, n, topo);
+  return hipGetLastError();
+}
+
 hipError_t launch_kd_build(float4* items, uint32_t n, int depthOverride, hipStream_t stream) {
   if (n < 2) return hipSuccess;
   // levels: ranges halve until they are empty; level L has at most 2^L ranges

@@ -92,6 +92,7 @@ struct rt_ctx {
   std::vector<void*> allocs;
   float4* phPos = nullptr;
   float4* phDir = nullptr;
+  uint4* phTopo = nullptr;  // explicit kd topology over phPos (rtk::launch_kd_topology)
   uint32_t* dTiles = nullptr;
   uint32_t nTiles = 0;
   TileKey tileKey;
@@ -587,7 +588,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   S.leafMul = getenv("RT_LEAFMUL") ? atoi(getenv("RT_LEAFMUL")) : bigTree ? 32 : 22;
   S.stealT = getenv("RT_STEALT") ? atoi(getenv("RT_STEALT")) : 8;
   S.refillT = getenv("RT_REFILLT") ? atoi(getenv("RT_REFILLT")) : bigTree ? 32 : 24;
-  S.phPos = S.phDir = nullptr;
+  S.phPos = S.phDir = nullptr, S.phTopo = nullptr;
   S.topK = 0;
   S.cam = sc->camera;
   {
@@ -627,6 +628,7 @@ void rt_destroy(rt_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->phPos) (void)hipFree(c->phPos);
   if (c->phDir) (void)hipFree(c->phDir);
+  if (c->phTopo) (void)hipFree(c->phTopo);
   if (c->dTiles) (void)hipFree(c->dTiles);
   if (c->dCounters) (void)hipFree(c->dCounters);
   if (c->dTileCounter) (void)hipFree(c->dTileCounter);
@@ -646,11 +648,13 @@ int rt_set_photons(rt_ctx* c, const float* pos3, const float* dir3, uint32_t n) 
   HIP_TRY(hipSetDevice(c->device));
   // the device scene forgets the old map BEFORE it is freed: a failed upload must leave
   // "no photons" behind (check_params then refuses use_photons), never dangling pointers
-  c->S.phPos = c->S.phDir = nullptr, c->S.n_photons = 0;
+  c->S.phPos = c->S.phDir = nullptr, c->S.phTopo = nullptr, c->S.n_photons = 0;
   float4 *oldP = c->phPos, *oldD = c->phDir;
-  c->phPos = c->phDir = nullptr;
+  uint4* oldT = c->phTopo;
+  c->phPos = c->phDir = nullptr, c->phTopo = nullptr;
   if (oldP) HIP_TRY(hipFree(oldP));
   if (oldD) HIP_TRY(hipFree(oldD));
+  if (oldT) HIP_TRY(hipFree(oldT));
   std::vector<float4> p(n), d(n);
   for (uint32_t i = 0; i < n; ++i) {
     p[i] = make_float4(pos3[3 * (size_t)i], pos3[3 * (size_t)i + 1], pos3[3 * (size_t)i + 2], 0.f);
@@ -658,13 +662,20 @@ int rt_set_photons(rt_ctx* c, const float* pos3, const float* dir3, uint32_t n) 
   }
   int rc = upload(&c->phPos, p.data(), n);
   if (rc == RT_OK) rc = upload(&c->phDir, d.data(), n);
-  if (rc != RT_OK) {  // drop whatever half of the map made it
+  if (rc == RT_OK && n) {  // the arrays come in tree order (kdtree.h:60-69): the explicit topology follows from it
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&c->phTopo), (size_t)n * sizeof(uint4));
+    if (he == hipSuccess) he = rtk::launch_kd_topology(c->phPos, n, c->phTopo, nullptr);
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    if (he != hipSuccess) rc = fail(RT_ERR_HIP, "photon topology failed: %s", hipGetErrorString(he));
+  }
+  if (rc != RT_OK) {  // drop whatever part of the map made it
     if (c->phPos) (void)hipFree(c->phPos);
     if (c->phDir) (void)hipFree(c->phDir);
-    c->phPos = c->phDir = nullptr;
+    if (c->phTopo) (void)hipFree(c->phTopo);
+    c->phPos = c->phDir = nullptr, c->phTopo = nullptr;
     return rc;
   }
-  c->S.phPos = c->phPos, c->S.phDir = c->phDir, c->S.n_photons = n;
+  c->S.phPos = c->phPos, c->S.phDir = c->phDir, c->S.phTopo = c->phTopo, c->S.n_photons = n;
   return RT_OK;
 }
 
@@ -1170,16 +1181,18 @@ int rt_build_photon_map(rt_ctx* c, uint32_t n_requested, uint32_t seed, uint32_t
   *n_stored = 0;
   HIP_TRY(hipSetDevice(c->device));
   // forget the old map first (see rt_set_photons)
-  c->S.phPos = c->S.phDir = nullptr, c->S.n_photons = 0;
+  c->S.phPos = c->S.phDir = nullptr, c->S.phTopo = nullptr, c->S.n_photons = 0;
   if (c->phPos) (void)hipFree(c->phPos);
   if (c->phDir) (void)hipFree(c->phDir);
-  c->phPos = c->phDir = nullptr;
+  if (c->phTopo) (void)hipFree(c->phTopo);
+  c->phPos = c->phDir = nullptr, c->phTopo = nullptr;
   if (n_requested == 0 || c->S.n_lights == 0) return RT_OK;
   const float lightPdf = 1.f / static_cast<float>(c->S.n_lights);  // PhotonMap.h:19-20
   const uint32_t perLight = static_cast<uint32_t>(static_cast<int>(static_cast<float>(static_cast<int>(n_requested)) * lightPdf));
   const uint32_t n = perLight * c->S.n_lights;
   if (n == 0) return RT_OK;
   float4 *slotPos = nullptr, *slotDir = nullptr, *items = nullptr, *phPos = nullptr, *phDir = nullptr;
+  uint4* phTopo = nullptr;
   uint32_t* dCount = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   auto cleanup = [&]() {
@@ -1204,7 +1217,9 @@ int rt_build_photon_map(rt_ctx* c, uint32_t n_requested, uint32_t seed, uint32_t
     he = rtk::launch_kd_build(items, m, -1, nullptr);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phPos), m * sizeof(float4));
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phDir), m * sizeof(float4));
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phTopo), m * sizeof(uint4));
     if (he == hipSuccess) he = rtk::launch_photon_gather(items, slotDir, m, phPos, phDir, nullptr, nullptr);
+    if (he == hipSuccess) he = rtk::launch_kd_topology(phPos, m, phTopo, nullptr);
   }
   if (he == hipSuccess) he = hipEventRecord(ev[2], nullptr);
   if (he == hipSuccess) he = hipDeviceSynchronize();
@@ -1218,10 +1233,11 @@ int rt_build_photon_map(rt_ctx* c, uint32_t n_requested, uint32_t seed, uint32_t
   if (he != hipSuccess) {
     if (phPos) (void)hipFree(phPos);
     if (phDir) (void)hipFree(phDir);
+    if (phTopo) (void)hipFree(phTopo);
     return fail(RT_ERR_HIP, "photon map build failed: %s", hipGetErrorString(he));
   }
-  c->phPos = phPos, c->phDir = phDir;
-  c->S.phPos = phPos, c->S.phDir = phDir, c->S.n_photons = m;
+  c->phPos = phPos, c->phDir = phDir, c->phTopo = phTopo;
+  c->S.phPos = phPos, c->S.phDir = phDir, c->S.phTopo = phTopo, c->S.n_photons = m;
   *n_stored = m;
   return RT_OK;
 }

@@ -44,6 +44,7 @@ struct DevScene {
   const uint32_t* meshVtxBegin;
   const float4* phPos;     // photons in kd-tree order: xyz + pad
   const float4* phDir;     // income direction xyz + weight
+  const uint4* phTopo;     // per photon: {left child | axis << 30, right child, parent's split coordinate, parent's axis} (kd_build.hip k_kd_topology)
   uint32_t n_tris, n_nodes, n_lights, n_photons;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
   uint32_t topK;           // node records [0, topK) are LDS-resident in the persistent kernel (set per launch)
@@ -120,6 +121,8 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n_
 // photon map on the device (kd_build.hip)
 hipError_t launch_photon_compact(const float4* slots, uint32_t n, float4* items, uint32_t* count, hipStream_t stream);
 hipError_t launch_kd_build(float4* items, uint32_t n, int depthOverride, hipStream_t stream);
+// explicit child / parent-split records of the median-implicit tree over phPos (what knn_query walks)
+hipError_t launch_kd_topology(const float4* phPos, uint32_t n, uint4* topo, hipStream_t stream);
 hipError_t launch_photon_gather(const float4* items, const float4* slotDir, uint32_t n, float4* phPos, float4* phDir,
                                 uint32_t* perm, hipStream_t stream);
 hipError_t launch_unit(uint32_t which, const void* in, void* out, uint32_t n, hipStream_t stream);

@@ -602,103 +602,89 @@ RT_DEV float photon_dist(const DevScene& S, uint32_t n, f3 p, float4& pos) {
   return dist3(mk(pos.x, pos.y, pos.z), p);
 }
 
+// kdtree::knearest (kdtree.h:87-107 recursion, :180-195 driver) over the tree's EXPLICIT topology (kd_build.hip
+// k_kd_topology: child indices, axis and the parent's split in a record per photon).  One flat loop, one node per
+// iteration, the same code for a lane that descends and a lane that comes back up:
+//   * visit (kdtree.h:88-99): distance, insert if d < m_bestdist; stop below a zero m_bestdist (:101);
+//   * descend into the near child (:102-104) and leave the far child on the lane's LDS stack — one word, its index;
+//   * a lane with nowhere to descend pops the next far child and, in the next iteration, FIRST applies kdtree.h:105
+//     (dx * dx >= m_bestdist, squared against plain, as there) with the m_bestdist of that moment and the split distance
+//     rebuilt from the child's own record (parent's coordinate - query coordinate: the float subtraction the parent's
+//     visit made) — a rejected child costs one iteration, nothing is unwound level by level.
+// Round 3's walk carried the implicit tree's (b, e, depth, pending / side / parity bit masks) and spent a third of its
+// vector instructions on range arithmetic, in two nested data-dependent loops whose trip counts the whole wave paid.
+// Result-preserving extra prune, as before (546 -> ~1/6 of the node visits on C3): every photon of a far subtree lies
+// beyond the split plane, so its float distance is >= |dx| * (1 - 1.5e-7) (monotone float subtraction; three roundings
+// under the square root, one on it), and m_bestdist never increases for k >= 2 (the new value is the second largest of
+// the old heap plus the new point): if |dx| * (1 - 4.8e-7) already reaches it, no node of that subtree can pass
+// d < m_bestdist (kdtree.h:92) and the heap — hence the result — is the same whether or not the subtree is walked.
+// (With k = 1 "the remaining k - 1" is empty and front() is the PREVIOUS insert, which may be larger than the one
+// before: there only the reference's own test runs.)  The reference's own test is much weaker whenever m_bestdist < 1.
 // After the call the heap holds the k results in ascending distance order.
-RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, float* dxStack) {
+constexpr uint32_t KD_NONE = 0x3fffffffu;
+RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, uint32_t* stack) {
   float4 pos;
   for (int j = 0; j < k; j++) H.set(j, photon_dist(S, (uint32_t)j, p, pos), (uint32_t)j);
   H.make(k);
   double bestdist = (double)H.D(0);
   float skip2 = (float)(bestdist * bestdist * (1.0 + 1e-6));
   uint32_t visited = 0;
-  const bool mono = k >= 2;  // m_bestdist is non-increasing (see the unwind below)
-  uint32_t pending = 0, wentLeft = 0, odd = 0;
-  uint32_t b = 0, e = S.n_photons;
-  int level = 0;
-  // One kdtree::knearest(node*) activation per iteration of ONE flat loop: a lane whose
-  // range ran empty unwinds to its next owed far side inside the same iteration, so all
-  // lanes of the wave arrive at the next node visit together (with a nested
-  // descend-until-empty loop, lanes that reached the bottom early waited for the
-  // deepest descent of the wave).  Invariant at the loop head: b < e.
-  for (;;) {
-    {
-      const uint32_t n = b + (e - b) / 2;
+  const bool mono = k >= 2;  // m_bestdist is non-increasing
+  uint32_t* top = stack;
+  *top = KD_NONE;  // row 0: the sentinel an empty stack pops
+  uint32_t cur = S.n_photons / 2u;  // the root: the median of [0, n)
+  bool popped = false;
+  while (cur != KD_NONE) {
+    const float4 P = S.phPos[cur];
+    const uint4 T = S.phTopo[cur];
+    bool go = true;
+    if (popped) {  // kdtree.h:105 for the activation that left this child behind, and the geometric prune
+      const float pc = T.w == 0u ? p.x : T.w == 1u ? p.y : p.z;
+      const double dxp = (double)(__uint_as_float(T.z) - pc);
+      go = !(dxp * dxp >= bestdist) && !(mono && (dxp < 0 ? -dxp : dxp) * (1.0 - 4.8e-7) >= bestdist);
+    }
+    uint32_t next = KD_NONE;
+    if (go) {
       ++visited;
-      // kdtree.h:90-92 compares the fp32 distance sqrt(d2), widened, with m_bestdist.  The
-      // correctly rounded root is only taken when d2 is not clearly out: d2 >= skip2 =
-      // m_bestdist^2 * (1 + 1e-6) rounded to float implies sqrtf(d2) >= m_bestdist (a
-      // correctly rounded sqrt is monotone and within 6e-8 relative), i.e. no insert.
-      pos = S.phPos[n];
-      const f3 dv = mk(pos.x, pos.y, pos.z) - p;
+      // kdtree.h:90-92 compares the fp32 distance sqrt(d2), widened, with m_bestdist.  The correctly rounded root is
+      // only taken when d2 is not clearly out: d2 >= skip2 = m_bestdist^2 * (1 + 1e-6) rounded to float implies
+      // sqrtf(d2) >= m_bestdist (a correctly rounded sqrt is monotone and within 6e-8 relative), i.e. no insert.
+      const f3 dv = mk(P.x, P.y, P.z) - p;
       const float d2 = dot3(dv, dv);
       if (!(d2 >= skip2)) {
         const float dn = __builtin_sqrtf(d2);
         if ((double)dn < bestdist) {
           H.pop(k);                       // pop_heap
           bestdist = (double)H.D(0);      // front() of the remaining k-1, then pop_back
-          H.set(k - 1, dn, n);            // push_back(*root)
-          H.push_up(k - 1, 0, dn, n);     // push_heap
+          H.set(k - 1, dn, cur);          // push_back(*root)
+          H.push_up(k - 1, 0, dn, cur);   // push_heap
           skip2 = (float)(bestdist * bestdist * (1.0 + 1e-6));
         }
       }
       if (bestdist != 0) {
-        const int axis = level % 3;
-        const float pc = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
-        const float nc = axis == 0 ? pos.x : axis == 1 ? pos.y : pos.z;
-        const float dx = nc - pc;
+        const uint32_t axis = T.x >> 30;
+        const float dx = axis == 0u ? dv.x : axis == 1u ? dv.y : dv.z;  // node coordinate - query coordinate (kdtree.h:102)
         const bool left = dx > 0.f;
-        // m_bestdist never increases (k >= 2), so a far side that both prunes below
-        // already reject now stays rejected: it is not even recorded
+        const uint32_t l = T.x & KD_NONE, r = T.y;
+        const uint32_t far = left ? r : l;
+        next = left ? l : r;
+        // m_bestdist never increases (k >= 2), so a far side that both tests already reject now stays rejected: it is
+        // not even recorded
+        // (the entry is stored above the top unconditionally and claimed by a select, as Trav::round does: one row
+        // beyond the deepest pending entry exists — the stack has a row per tree level plus the sentinel's)
         const double dxd = (double)dx;
-        if (!mono || (!(dxd * dxd >= bestdist) && !((dxd < 0 ? -dxd : dxd) * (1.0 - 4.8e-7) >= bestdist))) {
-          dxStack[level * BLOCK] = dx;
-          pending |= 1u << level;
-        }
-        wentLeft = left ? (wentLeft | (1u << level)) : (wentLeft & ~(1u << level));
-        odd = ((e - b) & 1u) ? (odd | (1u << level)) : (odd & ~(1u << level));
-        if (left) e = n;
-        else b = n + 1;
-        level++;
-        if (b < e) continue;  // descend
+        const bool out1 = dxd * dxd >= bestdist, out2 = (dxd < 0 ? -dxd : dxd) * (1.0 - 4.8e-7) >= bestdist;
+        const bool record = (far != KD_NONE) & (!mono | !(out1 | out2));
+        top[BLOCK] = far;
+        top += record ? BLOCK : 0;
       }
     }
-    // unwind to the deepest activation that still owes its far-side check
-    bool resumed = false;
-    while (pending) {
-      const int L = 31 - __clz(pending);
-      pending &= ~(1u << L);
-      const double dx = (double)dxStack[L * BLOCK];
-      if (dx * dx >= bestdist) continue;  // kdtree.h:105 (squared vs plain distance, as there)
-      // Result-preserving extra prune.  Every photon of the far subtree lies beyond
-      // the split plane, so its float distance is >= |dx| * (1 - 1.5e-7) (monotone
-      // float subtraction; three roundings under the sqrt, one on it), and
-      // m_bestdist never increases: if |dx| already exceeds it, no node of that
-      // subtree can pass `d < m_bestdist` (kdtree.h:92) and the heap — hence the
-      // result — is the same whether or not the subtree is walked.  (Monotone for
-      // k >= 2: the new value is the second largest of the old heap plus the new point.
-      // With k = 1 "the remaining k-1" is empty and front() is the PREVIOUS insert, which
-      // may be larger than the one before it: there only the reference's own test runs.)  The reference's
-      // own test is much weaker whenever m_bestdist < 1 (it needs |dx| >= sqrt of it):
-      // 546 -> ~1/6 of the node visits on the C3 workload.
-      if (mono && (dx < 0 ? -dx : dx) * (1.0 - 4.8e-7) >= bestdist) continue;
-      // Walk the range back UP from the current level to level L (amortised O(1) per
-      // visit; rebuilding it from the root cost O(L) per resume).  A range of s nodes
-      // splits at n = b + s/2 into a left child of s/2 and a right child of s - s/2 - 1
-      // nodes, so a child range, the side taken and the parity of s give the parent:
-      for (int l = level - 1; l >= L; l--) {
-        const uint32_t o = (odd >> l) & 1u;
-        if (wentLeft & (1u << l)) e = b + 2u * (e - b) + o;       // left child [b, n)
-        else b = e - (2u * (e - b) + 2u - o);                     // right child [n+1, e)
-      }
-      // ... and take the far child of the level-L node
-      const uint32_t m = b + (e - b) / 2;
-      if (wentLeft & (1u << L)) b = m + 1, wentLeft &= ~(1u << L);
-      else e = m, wentLeft |= (1u << L);
-      level = L + 1;
-      if (b >= e) continue;  // that side is empty: the activation returns at once (kdtree.h:88)
-      resumed = true;
-      break;
+    popped = next == KD_NONE;
+    if (popped) {
+      next = *top;
+      if (next != KD_NONE) top -= BLOCK;  // (the sentinel stays)
     }
-    if (!resumed) break;
+    cur = next;
   }
   H.sort(k);
   return visited;
@@ -745,7 +731,7 @@ RT_DEV f3 shade_photon(const DevScene& S, const RenderArgs& A, f3 rayDir, const 
   const Heap H{L.heap};
   const int k = (int)A.k;
   st.knn++;
-  const uint32_t vis = knn_query(S, point, k, H, reinterpret_cast<float*>(L.stack));
+  const uint32_t vis = knn_query(S, point, k, H, L.stack);
   if (STATS) st.kd += vis;
   const float4 far = S.phPos[H.I(k - 1)];
   const float r = dist3(mk(far.x, far.y, far.z), point);
@@ -1448,7 +1434,7 @@ __global__ __launch_bounds__(BLOCK) void k_knn(DevScene S, const float* __restri
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const Heap H{L.heap};
-  const uint32_t vis = knn_query(S, ld(q + 3 * (size_t)i), (int)k, H, reinterpret_cast<float*>(L.stack));
+  const uint32_t vis = knn_query(S, ld(q + 3 * (size_t)i), (int)k, H, L.stack);
   for (uint32_t j = 0; j < k; j++) {
     idx[(size_t)i * k + j] = H.I((int)j);
     dst[(size_t)i * k + j] = H.D((int)j);
