@@ -197,19 +197,28 @@ def cpu_baseline(ctx, scene_kind, mode, device, full=False):
     t_bvh = time.perf_counter() - t0
     out["port_bvh_value"] = (sb.rays_closest + sb.rays_shadow) / t_bvh / 1e6
     out["port_bvh_sample"] = "%s scene, 256x256, -m %d -N 8 (BASELINE config 1's size), oracle CPU BVH, 1 thread" % (scene_kind, mode)
-    # all host cores (pixel RNG mode: independent pixels, OpenMP; the reference itself cannot
-    # run multi-threaded: one global RNG)
+    # all host cores (pixel RNG mode: independent pixels, OpenMP over runs of 64 pixels; the reference itself cannot run
+    # multi-threaded: one global RNG).  The samples are sized for the host: a 512 x 512 frame is 4,096 work items
+    # (>= 16 per thread on a 256-thread box) and the spp is chosen for about 4 s at half-linear scaling, so every thread
+    # has work for the whole measurement; the thread count OpenMP actually used comes back from the oracle.
     threads = len(os.sched_getaffinity(0))
-    pp = pyrt.make_params(w, h, n, mode=mode, rng_mode=pyrt.RNG_PIXEL)
-    t0 = time.perf_counter()
-    _, _, s1 = orc.render(scene, pp, math_mode=orc.MATH_DET, threads=0)
-    out["port_loop_all_cores_value"] = (s1.rays_closest + s1.rays_shadow) / (time.perf_counter() - t0) / 1e6
-    pq = pyrt.make_params(512, 512, 16, mode=mode, rng_mode=pyrt.RNG_PIXEL)
-    s512 = pyrt.Scene(scene_kind, 512, 512)
-    t0 = time.perf_counter()
-    _, _, s2 = orc.render(s512, pq, math_mode=orc.MATH_DET, threads=0, accel=orc.ACCEL_OBVH)
-    out["port_bvh_all_cores_value"] = (s2.rays_closest + s2.rays_shadow) / (time.perf_counter() - t0) / 1e6
-    out["all_cores_threads"] = threads
+    per_sample = rays / float(w * h * n)
+    big_w = 512
+
+    def all_cores(rate1, accel):
+        want = max(1.0, rate1 * 1e6 * 0.5 * threads * 4.0)
+        spp = int(min(64, max(1, round(want / (big_w * big_w * per_sample)))))
+        sc = pyrt.Scene(scene_kind, big_w, big_w)
+        pa = pyrt.make_params(big_w, big_w, spp, mode=mode, rng_mode=pyrt.RNG_PIXEL)
+        t0 = time.perf_counter()
+        _, _, sa = orc.render(sc, pa, math_mode=orc.MATH_DET, threads=0, accel=accel)
+        dt = time.perf_counter() - t0
+        return (sa.rays_closest + sa.rays_shadow) / dt / 1e6, int(sa.reserved[0]), "%dx%dx%d spp, %.1f s" % (big_w, big_w, spp, dt)
+
+    out["port_loop_all_cores_value"], used1, out["port_loop_all_cores_sample"] = all_cores(out["port_loop_value"], orc.ACCEL_LOOP)
+    out["port_bvh_all_cores_value"], used2, out["port_bvh_all_cores_sample"] = all_cores(out["port_bvh_value"], orc.ACCEL_OBVH)
+    out["all_cores_threads"] = min(used1, used2)
+    out["all_cores_threads_available"] = threads
     # the GPU's exhaustive kernel (the reference algorithm itself on the GPU), bounded frame
     try:
         gp = pyrt.make_params(512, 512, 8, mode=mode, seed=1, accel=pyrt.ACCEL_BRUTE)
@@ -298,10 +307,27 @@ def main():
     # initialises the GPU.  At N > 1 rank 0 measures ITS shard (the counters describe one rank's
     # launch; the others wait for it in the rendezvous), so the line carries a per-rank roofline.
     pmc, pmc_source = None, "skipped (--no-pmc)" if args.no_pmc else "measured by rank 0 only"
+    # (no other rank may touch a GPU while the counter passes run — on a shared-GPU rehearsal their warm-up
+    # kernels would land in rank 0's device-wide counters, and under RCCL they would sit in their first collective for as
+    # long as the passes take.  The ranks of one launcher share its pid as parent: a marker file keyed by it is the gate.)
+    gate = os.path.join(tempfile.gettempdir(), "rt_bench_pmc_%d_%s.done" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
     if args.integrator != "fused":
         pmc_source = "skipped: the counters are defined for the fused kernel (the wavefront integrator is several kernels)"
     elif rank_env == 0 and not args.no_pmc:
-        pmc, pmc_source = pmc_measure(args, 0, world_env)
+        if os.path.exists(gate):
+            os.remove(gate)
+        try:
+            pmc, pmc_source = pmc_measure(args, 0, world_env)
+        finally:
+            if world_env > 1:
+                open(gate, "w").close()
+    elif world_env > 1 and not args.no_pmc:
+        t_gate = time.time()
+        while not os.path.exists(gate) and time.time() - t_gate < 3600:
+            time.sleep(0.2)
+    if world_env > 1:
+        # every rank builds the same host BVH: share the host's cores instead of 16 builder threads each
+        os.environ.setdefault("RT_BVH_THREADS", str(max(2, len(os.sched_getaffinity(0)) // world_env)))
 
     import torch
     import pyrt
@@ -380,7 +406,7 @@ def main():
     kernel_ms_min = -rdist.max_over_ranks(-avg_ms, dev)
     assemble_ms = (sum(a.elapsed_time(b) for a, b in asm_events) / len(asm_events)) if asm_events else 0.0
     exchange = ("none (one rank)" if world == 1 else
-                "%s gather of owned 8x8-pixel granules to rank 0 (%.2f MiB per rank and frame)" % (
+                "%s point-to-point sends of each rank's owned 8x8-pixel granules to rank 0 (%.2f MiB per rank and frame)" % (
                     backend, max(frame.counts) * 64 * 16 / 2**20))
 
     # ALGORITHMIC bytes per launch (SURVEY §8d per-unit figures x the units of this launch): 32 B
@@ -412,6 +438,8 @@ def main():
 
     if rank != 0:
         rdist.shutdown()  # (before rank 0 starts its CPU baseline: nobody waits on anybody after this)
+    elif world > 1 and os.path.exists(gate):
+        os.remove(gate)  # (every rank has passed it long ago: they all took part in the timed steps)
     if rank == 0:
         hbm_roof = {"bound": "hbm", "achieved": (hbm_bytes / secs / 1e9) if hbm_bytes and secs > 0 else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s"}

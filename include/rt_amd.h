@@ -157,7 +157,14 @@ typedef struct rt_bvh_info {
   float build_ms;      /* wall time of the build inside rt_create                */
   uint32_t builder;    /* RT_BVH_HOST / RT_BVH_DEVICE                            */
   uint32_t node_format;  /* RT_NODES_F16 / RT_NODES_Q8: what the pooled render kernel traverses */
+  uint32_t flags;        /* RT_BVH_FLAG_*                                                         */
 } rt_bvh_info;
+
+/* SHORT_RECIP: the render instances take 1 / det and 1 / length in the three- / five-instruction forms that are
+ * bit-identical to the IEEE operations inside the operand bounds rt_create checked (else they divide);
+ * RECIP_CHECK_FAILED: this device's own check of those forms (2^25 inputs at its first rt_create) disagreed with
+ * its division / sqrtf, so its contexts divide.  Same images either way.                                         */
+enum { RT_BVH_FLAG_SHORT_RECIP = 1, RT_BVH_FLAG_RECIP_CHECK_FAILED = 2 };
 
 typedef struct rt_ctx rt_ctx;
 

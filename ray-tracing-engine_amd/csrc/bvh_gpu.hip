@@ -33,6 +33,8 @@
 // Quality: measured nodes/ray vs the host SAH tree are in DESIGN.md.  Cost: a few ms for 1 M triangles.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstring>  // (rocPRIM's headers use memset without including it)
 #include <vector>
 
@@ -965,12 +967,18 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
     // the exact subtrees: scratch blocks of (triangles - 1) node slots each, built one workgroup per range ...
     hipLaunchKernelGGL(k_sub_sizes, dim3((nSub + 255) / 256), blk, 0, stream, subs, nSub, subSizes);
     GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subSizes, scratchOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
-    static bool ldsSet = false;
+    // (dynamic LDS beyond 64 KiB is granted per kernel AND per device — one process may build on several devices:
+    // rt_group —, so the grant is tracked per device, as rt_kernels.hip allow_big_lds does)
     const size_t ldsBytes = subtree_lds_bytes((int)kSubMax);
-    if (!ldsSet) {
-      GB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_subtree<(int)kSubMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)ldsBytes));
-      ldsSet = true;
+    {
+      static std::atomic<unsigned long long> ldsSet{0};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = -1;
+      if (dev < 0 || !(ldsSet.load() & (1ull << dev))) {
+        GB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_subtree<(int)kSubMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)ldsBytes));
+        if (dev >= 0) ldsSet.fetch_or(1ull << dev);
+      }
     }
     hipLaunchKernelGGL((k_subtree<(int)kSubMax>), dim3(nSub), dim3(kSubMax), ldsBytes, stream, subs, scratchOff, order, lo, hi, leafMax,
                        P.depthCap, scratch, subNodes, height);

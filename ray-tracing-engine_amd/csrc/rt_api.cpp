@@ -112,6 +112,8 @@ struct rt_ctx {
   size_t wfCap = 0;
   void* wfBlock = nullptr;
   uint32_t builder = RT_BVH_HOST;
+  bool broken = false;  // the device tree is in an unknown state (rt_bvh_tune could not restore it): launches are refused
+  uint32_t recipCheck = 0;  // 0: short reciprocal forms not wanted (operand bounds), 1: verified on this device, 2: self-check FAILED (dividing)
   uint32_t nodeFormat = RT_NODES_F16;  // what the pooled render kernel and rt_trace traverse
   float buildMs = 0.f;
   uint32_t numCUs = 0;
@@ -242,6 +244,7 @@ int ensure_granules(rt_ctx* c, const rt_params* p, uint32_t rank, rt_ctx::GranLi
 
 int check_params(const rt_ctx* c, const rt_params* p) {
   if (!p) return fail(RT_ERR_INVALID, "params is null");
+  if (c->broken) return fail(RT_ERR_STATE, "the context's device tree is in an unknown state (a failed rt_bvh_tune): destroy it");
   if (p->width == 0 || p->height == 0 || p->width > 65535u || p->height > 65535u)
     return fail(RT_ERR_INVALID, "image size %ux%u out of range", p->width, p->height);
   if (p->spp == 0) return fail(RT_ERR_INVALID, "spp must be >= 1");
@@ -581,6 +584,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
         if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "short reciprocal / square root self-check on device %d: %s\n", c->device, ok ? "bit-identical" : "MISMATCH, dividing");
       }
       if (!it->second) S.slowRecip = 1u;
+      c->recipCheck = it->second ? 1u : 2u;
     }
   }
   const bool bigTree = S.n_nodes > 65536;
@@ -888,6 +892,7 @@ int rt_bvh_info_get(rt_ctx* c, rt_bvh_info* out) {
   out->build_ms = c->buildMs;
   out->builder = c->builder;
   out->node_format = c->nodeFormat;
+  out->flags = (c->S.slowRecip ? 0u : (uint32_t)RT_BVH_FLAG_SHORT_RECIP) | (c->recipCheck == 2u ? (uint32_t)RT_BVH_FLAG_RECIP_CHECK_FAILED : 0u);
   return RT_OK;
 }
 
@@ -1090,9 +1095,9 @@ int rt_bvh_tune(rt_ctx* c, const rt_params* probe, double budget_seconds, uint32
   // whose probe is too small for their triangle count).
   rtbvh::TuneReport rep;
   bool kept = true;
+  const std::vector<rtbvh::Node> original = c->bvh.nodes;
+  const uint32_t depth0 = c->bvh.maxDepth;
   try {
-    const std::vector<rtbvh::Node> original = c->bvh.nodes;
-    const uint32_t depth0 = c->bvh.maxDepth;
     rt_params pv = p;
     pv.seed = p.seed ^ 0x9e3779b9u;
     auto referee = [&]() {
@@ -1112,9 +1117,31 @@ int rt_bvh_tune(rt_ctx* c, const rt_params* probe, double budget_seconds, uint32
   } catch (const std::exception& e) {
     err = e.what();
   }
-  if (err.empty()) upload();
+  if (!err.empty()) {
+    // a failed probe, upload or builder step: the context goes back to the tree it came with, host AND device side
+    // (the device may hold whichever candidate was uploaded last)
+    const std::string why = err;
+    err.clear();
+    try {
+      c->bvh.nodes = original, c->bvh.maxDepth = depth0;
+      rtbvh::relayoutAndPack(c->bvh);
+    } catch (const std::exception& e) {
+      err = e.what();
+    }
+    if (err.empty()) upload();
+    (void)hipFree(dAcc);
+    if (!err.empty()) {  // not even that: the device tree is unknown, the context must not render again
+      c->broken = true;
+      return fail(RT_ERR_STATE, "rt_bvh_tune: %s; restoring the original tree failed too (%s): the context is unusable", why.c_str(), err.c_str());
+    }
+    return fail(RT_ERR_HIP, "rt_bvh_tune: %s (the original tree is back in place)", why.c_str());
+  }
+  upload();
   (void)hipFree(dAcc);
-  if (!err.empty()) return fail(RT_ERR_HIP, "rt_bvh_tune: %s", err.c_str());
+  if (!err.empty()) {
+    c->broken = true;
+    return fail(RT_ERR_STATE, "rt_bvh_tune: %s: the context is unusable", err.c_str());
+  }
   if (out) out->probes = rep.probes, out->accepted = kept ? rep.accepted : 0u, out->cost_before = rep.cost0, out->cost_after = kept ? rep.cost1 : rep.cost0, out->seconds = rep.seconds;
   return RT_OK;
 }

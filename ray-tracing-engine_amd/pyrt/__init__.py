@@ -83,7 +83,7 @@ class TuneReport(C.Structure):
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_tri_records", C.c_uint32), ("max_depth", C.c_uint32),
                 ("leaf_max", C.c_uint32), ("pad", C.c_float), ("build_ms", C.c_float), ("builder", C.c_uint32),
-                ("node_format", C.c_uint32)]
+                ("node_format", C.c_uint32), ("flags", C.c_uint32)]
 
 
 RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3)])

@@ -4,10 +4,11 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 The path shards by 8x8-pixel tiles (rt_params.rank/world/tile): every rank
 integrates ALL samples of the pixels it owns, in order, into a zero-initialised
 full-frame accumulator {sum r, g, b, primary-hit count}.  The only exchange step
-is the assembly of the frame on rank 0: FrameAssembler gathers each rank's OWNED
-granules (w*h*16/N bytes per rank: 2 MiB at 1024^2 and 8 ranks, each over its own xGMI
-link to rank 0), so the N-GPU frame is bit-identical to the 1-GPU frame by construction
-— pixels are copied, never summed.  reduce_frame (a full-frame SUM reduce of mostly
+is the assembly of the frame on rank 0: FrameAssembler sends each rank's OWNED
+granules to rank 0 — point to point, exactly counts[r] granules (w*h*16/N bytes per
+rank: 2 MiB at 1024^2 and 8 ranks, each over its own xGMI link to rank 0; one batch of
+isend / irecv = one ncclGroupStart ... ncclGroupEnd under RCCL) — so the N-GPU frame is
+bit-identical to the 1-GPU frame by construction: pixels are copied, never summed.  reduce_frame (a full-frame SUM reduce of mostly
 zeros, exact for the same reason) is kept as the reference exchange for the tests.
 """
 import os
@@ -71,9 +72,10 @@ def owned_granule_index(width, height, rank, world, tile):
 
 class FrameAssembler:
     """Assembles the tile-sharded frame on rank 0 by moving only OWNED pixels: every rank
-    packs its 8x8 granules ([granule][64] float4), one gather brings them to rank 0 (1/N of
-    the frame per rank instead of a full-frame SUM reduce of mostly zeros), rank 0 scatters
-    them.  On a GPU the pack/scatter are the library's kernels (rt_pack_owned_device /
+    packs its 8x8 granules ([granule][64] float4), one batch of point-to-point sends brings
+    them to rank 0 (exactly counts[r] granules from rank r: 1/N of the frame per rank instead
+    of a full-frame SUM reduce of mostly zeros, and nothing padded to the largest share),
+    rank 0 scatters them.  On a GPU the pack/scatter are the library's kernels (rt_pack_owned_device /
     rt_unpack_owned_device); on CPU tensors (gloo tests) the same order in numpy."""
 
     def __init__(self, ctx, params, rank, world, device):
@@ -89,11 +91,10 @@ class FrameAssembler:
         else:
             self.index = [owned_granule_index(self.w, self.h, r, world, self.tile) for r in range(world)]
             self.counts = [len(ix) for ix in self.index]
-        self.maxc = max(self.counts)
         # gloo cannot move device tensors: stage through the host in rehearsal mode
         self.stage_dev = "cpu" if (self.cuda and self.backend == "gloo") else device
-        self.packed = torch.zeros((self.maxc * 64, 4), dtype=torch.float32, device=device)
-        self.recv = ([torch.zeros((self.maxc * 64, 4), dtype=torch.float32, device=self.stage_dev) for _ in range(world)]
+        self.packed = torch.zeros((self.counts[rank] * 64, 4), dtype=torch.float32, device=device)
+        self.recv = ([None] + [torch.zeros((self.counts[r] * 64, 4), dtype=torch.float32, device=self.stage_dev) for r in range(1, world)]
                      if rank == 0 else None)
 
     def assemble(self, accum, stream=0):
@@ -112,10 +113,19 @@ class FrameAssembler:
             ix = torch.from_numpy(self.index[self.rank].reshape(-1).clip(min=0))
             self.packed[: len(ix)] = accum.view(-1, 4)[ix]
             send = self.packed
-        dist.gather(send, self.recv if self.rank == 0 else None, dst=0)
+        # rank r > 0 -> rank 0, counts[r] granules each (rank 0's own granules are already in place)
+        if self.rank == 0:
+            ops = [dist.P2POp(dist.irecv, self.recv[r], r) for r in range(1, self.world) if self.counts[r]]
+        else:
+            ops = [dist.P2POp(dist.isend, send, 0)] if self.counts[self.rank] else []
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         self.calls = getattr(self, "calls", 0) + 1
         if self.rank == 0:
             for r in range(1, self.world):
+                if not self.counts[r]:
+                    continue
                 if self.cuda:
                     buf = self.recv[r] if self.stage_dev != "cpu" else self.recv[r].to(accum.device)
                     self.ctx.unpack_owned(self.params, r, buf.data_ptr(), accum.data_ptr(), stream)

@@ -126,7 +126,9 @@ def test_bench_spawns_its_own_launcher(tmp_path):
     assert roof["valu_issue"]["frac"] is not None and roof["traffic"] is not None and "1/3" in roof["scope"]
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
     assert cfg["assemble_ms"] > 0 and cfg["kernel_ms_max_over_ranks"] >= cfg["kernel_ms_min_over_ranks"] > 0
-    assert "gather of owned 8x8-pixel granules" in cfg["exchange"]
+    assert "sends of each rank's owned 8x8-pixel granules" in cfg["exchange"]
+    # round 4: the all-cores CPU figures say how many threads the oracle's OpenMP loop really ran on
+    assert d["cpu_baseline"]["all_cores_threads"] >= 1 and d["cpu_baseline"]["port_bvh_all_cores_value"] > d["cpu_baseline"]["port_bvh_value"]
 
 
 def test_progressive_update_ppm_matches_the_reference_semantics(tmp_path):

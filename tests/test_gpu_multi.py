@@ -23,7 +23,8 @@ def bits(a):
 
 
 @pytest.mark.parametrize("kind,w,h,spp,mode,ranks", [("lowres", 200, 136, 6, 1, 2), ("cubes", 45, 37, 5, 1, 3),
-                                                     ("hires", 256, 256, 4, 1, 4), ("cubes", 64, 64, 3, 0, 6)])
+                                                     ("hires", 256, 256, 4, 1, 4), ("cubes", 64, 64, 3, 0, 6),
+                                                     ("lowres", 256, 192, 2, 1, 8)])  # (8: the driver's --gpus 8 shape)
 def test_group_frame_equals_single_context_frame(kind, w, h, spp, mode, ranks):
     s = pyrt.Scene(kind, w, h)
     bg = pyrt.background(w, h)
