@@ -512,6 +512,11 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   }
   c->buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count();
   UP(mats, sc->materials, sc->n_meshes);
+  {
+    std::vector<rtd::DevMat> dm(sc->n_meshes);
+    for (uint32_t m = 0; m < sc->n_meshes; ++m) dm[m] = rtd::make_dev_mat(sc->materials[m]);
+    UP(matsDev, dm.data(), dm.size());
+  }
   UP(lights, sc->lights, sc->n_lights);
   UP(meshTriBegin, sc->mesh_tri_begin, sc->n_meshes + 1);
   UP(meshVtxBegin, sc->mesh_vtx_begin, sc->n_meshes + 1);

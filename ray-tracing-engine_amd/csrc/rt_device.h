@@ -192,12 +192,43 @@ RT_DEV float g_schlick(float alpha, f3 w, f3 n) {
   float nw = dot3(n, w);
   return nw / (nw * (1 - k) + k);
 }
+// What Material.h:25-70 computes from the material ALONE, hoisted to rt_create (rt_api.cpp fills it with the same IEEE
+// operations on the same operands: albedo / float(M_PI) then * kd, 1 - kd, alpha * alpha, 1 - F0, k = float(double(alpha) *
+// sqrt(2 / pi)), 1 - k — the bits the per-vertex code formed): 3 divisions, a double product and a dozen other operations
+// per vertex and four more double products per vertex in gSchlick that no longer run in the pooled kernel.
+struct DevMat {
+  float kdDiffuse[3], oneMinusKd;
+  float f0[3], alpha;
+  float oneMinusF0[3], a2;
+  float k, oneMinusK, pad[2];
+};
+static_assert(sizeof(DevMat) == 64, "device material record");
+inline DevMat make_dev_mat(const rt_material& m) {  // (host side, rt_create)
+  DevMat d;
+  for (int c = 0; c < 3; ++c) {
+    const float diffuse = m.albedo[c] / 3.14159274f;  // albedo / float(M_PI)
+    d.kdDiffuse[c] = m.kd * diffuse;
+    d.f0[c] = m.f0[c];
+    d.oneMinusF0[c] = 1.f - m.f0[c];
+  }
+  d.oneMinusKd = 1 - m.kd;
+  d.alpha = m.alpha, d.a2 = m.alpha * m.alpha;
+  d.k = (float)((double)m.alpha * 0x1.9884533d43651p-1 /* == sqrt(2. / M_PI) in double */);
+  d.oneMinusK = 1 - d.k;
+  d.pad[0] = d.pad[1] = 0.f;
+  return d;
+}
+RT_DEV float g_schlick_k(float k, float oneMinusK, f3 w, f3 n) {
+  float nw = dot3(n, w);
+  return nw / (nw * oneMinusK + k);
+}
 // evaluateColorResponse split in two: what depends on (material, normal, wo) only is
 // computed once per vertex, the rest once per light.  Same operations on the same
 // operands in the same order as the one-piece form, so the same bits.
 struct BsdfBase {
   f3 n, wo, F0, oneMinusF0, kdDiffuse;
   float alpha, a2, gwo, nwo, oneMinusKd;
+  float k, oneMinusK;  // gSchlick's constants (set by both constructors)
 };
 template <bool FAST = false>
 RT_DEV BsdfBase bsdf_base(const rt_material& m, f3 normal, f3 wo_in) {
@@ -209,6 +240,20 @@ RT_DEV BsdfBase bsdf_base(const rt_material& m, f3 normal, f3 wo_in) {
   B.nwo = dot3(B.n, B.wo);
   const f3 diffuse = ld(m.albedo) / 3.14159274f;  // albedo / float(M_PI)
   B.kdDiffuse = m.kd * diffuse, B.oneMinusKd = 1 - m.kd;
+  B.k = (float)((double)m.alpha * 0x1.9884533d43651p-1), B.oneMinusK = 1 - B.k;
+  return B;
+}
+// the same from the hoisted record
+template <bool FAST = false>
+RT_DEV BsdfBase bsdf_base(const DevMat& m, f3 normal, f3 wo_in) {
+  BsdfBase B;
+  B.n = unit3<FAST>(normal), B.wo = unit3<FAST>(wo_in);
+  B.alpha = m.alpha, B.a2 = m.a2;
+  B.F0 = ld(m.f0), B.oneMinusF0 = ld(m.oneMinusF0);
+  B.k = m.k, B.oneMinusK = m.oneMinusK;
+  B.gwo = g_schlick_k(B.k, B.oneMinusK, B.wo, B.n);
+  B.nwo = dot3(B.n, B.wo);
+  B.kdDiffuse = ld(m.kdDiffuse), B.oneMinusKd = m.oneMinusKd;
   return B;
 }
 template <bool FAST = false>
@@ -220,7 +265,7 @@ RT_DEV f3 bsdf_apply(const BsdfBase& B, f3 wi_in) {
   double c = (double)dot3(wi, wh);
   float f5 = (float)rt_pow5(1 - (c > 0.0 ? c : 0.0));  // fmax(0, c); NaN -> 0 like fmax
   f3 F = B.F0 + B.oneMinusF0 * f5;
-  float G = g_schlick(B.alpha, wi, B.n) * B.gwo;
+  float G = g_schlick_k(B.k, B.oneMinusK, wi, B.n) * B.gwo;
   float denom = (float)(4. * (double)dot3(B.n, wi) * (double)B.nwo);
   f3 spec = D * F * G / denom;
   f3 r = B.kdDiffuse + B.oneMinusKd * spec;

@@ -7,6 +7,7 @@
 
 #include "bvh_build.h"
 #include "rt_amd.h"
+#include "rt_device.h"
 
 #define RTK_KMAX 16  // photon k-heap slots per lane (LDS budget, rt_kernels.hip)
 
@@ -39,6 +40,7 @@ struct DevScene {
   const float* vpos;       // [n_vertices][3]
   const float* vnrm;       // [n_vertices][3]
   const rt_material* mats; // [n_meshes]
+  const rtd::DevMat* matsDev;  // [n_meshes] the same with the per-material constants of Material.h:25-70 worked out (rt_device.h)
   const rt_light* lights;  // [n_lights]
   const uint32_t* meshTriBegin;
   const uint32_t* meshVtxBegin;

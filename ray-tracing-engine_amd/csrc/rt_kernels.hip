@@ -753,7 +753,7 @@ RT_DEV f3 shade_photon(const DevScene& S, const RenderArgs& A, f3 rayDir, const 
 template <bool BRUTE, bool STATS>
 RT_DEV f3 shade_direct_seq(const DevScene& S, Rng& g, f3 rayDir, const HitRec& h, uint32_t* stack, f3 hitNormal,
                            f3 point, LaneStats& st) {
-  const BsdfBase base = bsdf_base(S.mats[h.mesh], hitNormal, -rayDir);  // the light-independent half, once
+  const BsdfBase base = bsdf_base(S.matsDev[h.mesh], hitNormal, -rayDir);  // the light-independent half, once
   f3 color = mk(0.f, 0.f, 0.f);
   for (uint32_t li = 0; li < S.n_lights; li++) {
     const rt_light Lt = S.lights[li];
@@ -1000,7 +1000,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   point = pt;
   if (bounce && !CP2) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
   if (alive) {
-    const BsdfBase base = bsdf_base<FR>(S.mats[mesh], hitNormal, -rayDir);  // the light-independent half, once
+    const BsdfBase base = bsdf_base<FR>(S.matsDev[mesh], hitNormal, -rayDir);  // the light-independent half, once
     for (uint32_t l = 0; l < nl; l++) {
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
       const f3 toLight = CP ? light_point(S.lights[l], fp[VP_DIR + (2 * l + 0) * 64 + lane], fp[VP_DIR + (2 * l + 1) * 64 + lane]) - pt
