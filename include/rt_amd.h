@@ -94,7 +94,9 @@ typedef struct rt_options {
                               traverse.  AUTO picks per scene; the hits are the same either way  */
   uint32_t reserved[4];
 } rt_options;
-enum { RT_BVH_HOST = 0, RT_BVH_DEVICE = 1 };
+/* RT_BVH_HYBRID: the host builder's own top, stopped at parts of <= 1,024 triangles, each of which becomes one exact
+ * SAH subtree built by one workgroup on the device (where the host build spends most of its time).                 */
+enum { RT_BVH_HOST = 0, RT_BVH_DEVICE = 1, RT_BVH_HYBRID = 2 };
 /* RT_NODES_F16: 32-byte records, 12 binary16 box planes + 2 child refs (two 16-byte requests per visit).
  * RT_NODES_Q8:  16-byte records, 12 8-bit box planes in the frame of the record's 16-KiB block + one
  *               packed child word (ONE request per visit), nodes and triangle records in one array.   */
@@ -155,7 +157,7 @@ typedef struct rt_bvh_info {
   uint32_t n_nodes, n_tri_records, max_depth, leaf_max;
   float pad;           /* absolute box padding used                             */
   float build_ms;      /* wall time of the build inside rt_create                */
-  uint32_t builder;    /* RT_BVH_HOST / RT_BVH_DEVICE                            */
+  uint32_t builder;    /* RT_BVH_HOST / RT_BVH_DEVICE / RT_BVH_HYBRID            */
   uint32_t node_format;  /* RT_NODES_F16 / RT_NODES_Q8: what the pooled render kernel traverses */
   uint32_t flags;        /* RT_BVH_FLAG_*                                                         */
 } rt_bvh_info;

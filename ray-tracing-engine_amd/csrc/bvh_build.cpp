@@ -9,6 +9,7 @@
 #include <cstring>
 #include <exception>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -48,6 +49,10 @@ struct Builder {
   uint32_t leafMax;
   int depthCap = kMaxDepth - 1;  // deepest leaf level the tree may use
   uint32_t grain = ~0u;          // ranges above this many primitives fork a thread
+  // buildTop: ranges of at most this many primitives are not split here (0 = build the whole tree)
+  uint32_t cutoff = 0;
+  std::vector<TopBuilt::Part> parts;
+  std::mutex partsLock;
 
   Builder(const rt_scene_desc& s, Built& o, uint32_t lm) : sc(s), out(o), leafMax(lm) {}
 
@@ -222,6 +227,11 @@ struct Builder {
       // met lowest id first (not required for correctness, just tidy)
       std::sort(prims.begin() + b, prims.begin() + e, [](const Prim& p, const Prim& q) { return p.id < q.id; });
       return encodeLeaf(b, e - b);
+    }
+    if (cutoff && e - b <= cutoff) {  // a part: its subtree is built elsewhere (bvh_gpu.hip k_subtree)
+      std::lock_guard<std::mutex> lock(partsLock);
+      parts.push_back(TopBuilt::Part{b, e, (uint32_t)depth, 0u, 0u});
+      return (int32_t)~(kPartFlag | (uint32_t)(parts.size() - 1));
     }
     if (depth >= kMaxDepth - 1) throw std::runtime_error("BVH depth budget exceeded");
     const uint32_t m = split(b, e, depth);
@@ -1164,6 +1174,83 @@ void decodeQ8(const Built& b, uint32_t byteOffset, float lo[2][3], float hi[2][3
 void relayoutAndPack(Built& b) {
   relayoutTop(b.nodes, kTopNodes);
   packNodes(b);
+}
+
+void buildTop(const rt_scene_desc& sc, uint32_t leafMax, uint32_t cutoff, TopBuilt& out, uint32_t threads) {
+  if (leafMax == 0) leafMax = 2;
+  if (leafMax > 8) leafMax = 8;
+  if (cutoff <= leafMax) throw std::runtime_error("buildTop: the cutoff must exceed the leaf size");
+  if (sc.n_triangles == 0 || sc.n_triangles >= (1u << 28)) throw std::runtime_error("triangle count out of range");
+  if (sc.mesh_tri_begin[sc.n_meshes] != sc.n_triangles || sc.mesh_vtx_begin[sc.n_meshes] != sc.n_vertices)
+    throw std::runtime_error("mesh offset tables inconsistent with counts");
+  Built scratch;  // (the Builder writes triangle records and the plan's numbers here; only the numbers are kept)
+  scratch.leafMax = leafMax;
+  Builder B(sc, scratch, leafMax);
+  B.cutoff = cutoff;
+  const char* slack = getenv("RT_BVH_SLACK");
+  B.depthCap = std::min(kMaxDepth - 1, B.levelsFor(sc.n_triangles) + (slack ? atoi(slack) : defaultDepthSlack(B.levelsFor(sc.n_triangles))));
+  B.prims.resize(sc.n_triangles);
+  float maxAbs = 0.f;
+  for (uint32_t m = 0; m < sc.n_meshes; ++m) {
+    if (sc.mesh_tri_begin[m] > sc.mesh_tri_begin[m + 1]) throw std::runtime_error("mesh_tri_begin not monotone");
+    for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; ++t) {
+      Prim& p = B.prims[t];
+      p.id = t;
+      p.box.reset();
+      for (int k = 0; k < 3; ++k) {
+        const uint32_t v = sc.tri_vtx[3 * static_cast<size_t>(t) + k];
+        if (v < sc.mesh_vtx_begin[m] || v >= sc.mesh_vtx_begin[m + 1]) throw std::runtime_error("triangle references a vertex outside its mesh");
+        const float* q = sc.vertex_pos + 3 * static_cast<size_t>(v);
+        for (int a = 0; a < 3; ++a) {
+          if (!std::isfinite(q[a])) throw std::runtime_error("non-finite vertex position");
+          maxAbs = std::max(maxAbs, std::fabs(q[a]));
+        }
+        p.box.grow(q);
+      }
+      for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+      p.c[3] = -std::log2(std::max({p.box.hi[0] - p.box.lo[0], p.box.hi[1] - p.box.lo[1], p.box.hi[2] - p.box.lo[2], 1e-30f}));
+    }
+  }
+  float padRef = std::max(1.f, maxAbs);
+  for (int a = 0; a < 3; ++a)
+    if (std::isfinite(sc.camera.position[a])) padRef = std::max(padRef, std::fabs(sc.camera.position[a]));
+  for (uint32_t l = 0; l < sc.n_lights; ++l)
+    for (int a = 0; a < 3; ++a)
+      if (std::isfinite(sc.lights[l].position[a])) padRef = std::max(padRef, std::fabs(sc.lights[l].position[a]));
+  scratch.pad = 6e-5f * padRef;  // (recurse pads the boxes with it)
+  uint32_t nthreads = threads ? threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("RT_BVH_THREADS")) nthreads = std::max(1, atoi(e));
+  B.grain = nthreads > 1 ? std::max<uint32_t>(8192u, sc.n_triangles / (4u * nthreads)) : ~0u;
+  if (sc.n_triangles <= cutoff) throw std::runtime_error("buildTop: the scene is a single part");
+  Box root;
+  Builder::Sub top;
+  B.recurse(0, sc.n_triangles, 0, root, top);
+  out.nodes.swap(top.nodes);
+  smallerChildFirst(out.nodes);
+  relayoutTop(out.nodes, kTopNodes);
+  // parts numbered by their place in the order (the threads registered them as they came), then their referrers
+  std::vector<uint32_t> idx(B.parts.size());
+  for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return B.parts[x].b < B.parts[y].b; });
+  std::vector<uint32_t> newOf(idx.size());
+  out.parts.resize(idx.size());
+  for (uint32_t k = 0; k < idx.size(); ++k) newOf[idx[k]] = k, out.parts[k] = B.parts[idx[k]];
+  out.maxDepth = top.maxDepth;
+  for (uint32_t i = 0; i < out.nodes.size(); ++i)
+    for (int c = 0; c < 2; ++c) {
+      const int32_t ref = out.nodes[i].child[c];
+      if (ref < 0 && ((~(uint32_t)ref) & kPartFlag)) {
+        const uint32_t k = newOf[(~(uint32_t)ref) & (kPartFlag - 1u)];
+        out.nodes[i].child[c] = (int32_t)~(kPartFlag | k);
+        out.parts[k].parent = i, out.parts[k].slot = (uint32_t)c;
+      }
+    }
+  out.order.resize(sc.n_triangles);
+  for (uint32_t i = 0; i < sc.n_triangles; ++i) out.order[i] = B.prims[i].id;
+  out.leafMax = leafMax, out.depthCap = B.depthCap, out.pad = scratch.pad, out.originBound = 16.f * padRef;
+  int e = 0;
+  std::frexp(32768.f / std::max(maxAbs + out.pad, 1e-30f), &e);
+  out.boxScale = std::ldexp(1.f, std::min(std::max(e - 1, -100), 100));
 }
 
 void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threads) {

@@ -143,6 +143,29 @@ ScenePlan planScene(const rt_scene_desc& scene, uint32_t leafMax);
 uint16_t toHalfDirected(float x, bool up);
 float halfToFloat(uint16_t h);
 
+// The TOP of the host builder's tree alone (the hybrid builder, rt_options.bvh_builder = RT_BVH_HYBRID): build() run
+// down to ranges of at most `cutoff` triangles — the same split choices (binned SAH with the size axis above 4,096
+// triangles, the exact sweep below, the depth budget) — and stopped there.  Every such range ("part") becomes one exact
+// subtree on the device (bvh_gpu.hip k_subtree: one workgroup per part), which is where the host build spends most of
+// its time.  child refs of `nodes`: >= 0 a top node, < 0 either a leaf (as in Node) or, with bit 30 of ~ref set, the
+// part ~ref & 0x3fffffff.
+struct TopBuilt {
+  struct Part {
+    uint32_t b, e;      // range of `order`
+    uint32_t depth;     // depth of the part's root node in the whole tree
+    uint32_t parent;    // top node that refers to it, and which of its children
+    uint32_t slot;
+  };
+  std::vector<Node> nodes;      // most-visited first (relayoutTop), child 0 = the smaller box
+  std::vector<uint32_t> order;  // triangle ids: the leaf order above the parts, each part's range contiguous
+  std::vector<Part> parts;      // ascending by b
+  uint32_t leafMax = 2, maxDepth = 0;  // maxDepth: deepest leaf / part root of the top
+  int depthCap = kMaxDepth - 1;
+  float pad = 0.f, originBound = 0.f, boxScale = 1.f;
+};
+constexpr uint32_t kPartFlag = 0x40000000u;
+void buildTop(const rt_scene_desc& scene, uint32_t leafMax, uint32_t cutoff, TopBuilt& out, uint32_t threads = 0);
+
 // Throws std::runtime_error on an inconsistent scene description.
 // threads: builder threads (0 = one per hardware thread, at most 16); the result does not
 // depend on it.

@@ -1010,4 +1010,120 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
   return hipSuccess;
 }
 
+// The HYBRID build (rt_options.bvh_builder = RT_BVH_HYBRID): the host builder's own top (rtbvh::buildTop: its split
+// choices down to parts of <= kSubMax triangles) and, below it, the exact subtrees of step 6 — one workgroup per part.
+// The host spends most of a build in those bottom levels (sorts of every range of <= 4,096 triangles along four axes);
+// the top is a few binned passes.  Same arrays out as gpu_bvh_build.
+hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, uint32_t n, const rtbvh::TopBuilt& top, GpuBvh* out,
+                                  hipStream_t stream) {
+  *out = GpuBvh{};
+  const uint32_t nTop = (uint32_t)top.nodes.size(), nSub = (uint32_t)top.parts.size();
+  if (n == 0 || nTop == 0 || top.order.size() != n) return hipErrorInvalidValue;
+  for (const rtbvh::TopBuilt::Part& p : top.parts)
+    if (p.e <= p.b || p.e - p.b > kSubMax || p.e > n || p.parent >= nTop || p.slot > 1u) return hipErrorInvalidValue;
+  float4 *lo = nullptr, *hi = nullptr, *nodesF = nullptr, *tris = nullptr, *trisRef = nullptr, *scratch = nullptr;
+  uint4* nodes16 = nullptr;
+  int* cb = nullptr;
+  uint32_t *order = nullptr, *subSizes = nullptr, *scratchOff = nullptr, *subNodes = nullptr, *finalOff = nullptr, *height = nullptr;
+  SubItem* subs = nullptr;
+  void* tmp = nullptr;
+  bool keepOutputs = false;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)lo, (void*)hi, (void*)cb, (void*)order, (void*)subSizes, (void*)scratchOff, (void*)subNodes, (void*)finalOff,
+                    (void*)height, (void*)scratch, (void*)subs, tmp})
+      if (p) (void)hipFree(p);
+    if (!keepOutputs)
+      for (void* p : {(void*)nodes16, (void*)nodesF, (void*)tris, (void*)trisRef})
+        if (p) (void)hipFree(p);
+  };
+  const uint32_t maxNodes = n + nTop;
+  const size_t nS = nSub ? nSub : 1u;
+  GB_TRY(hipMalloc((void**)&lo, (size_t)n * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&hi, (size_t)n * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&cb, 6 * sizeof(int)));
+  GB_TRY(hipMalloc((void**)&order, (size_t)n * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&subs, nS * sizeof(SubItem)));
+  GB_TRY(hipMalloc((void**)&subSizes, nS * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&scratchOff, nS * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&subNodes, nS * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&finalOff, nS * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&height, sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&scratch, 4 * (size_t)n * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&nodes16, 2 * (size_t)maxNodes * sizeof(uint4)));
+  GB_TRY(hipMalloc((void**)&nodesF, 4 * (size_t)maxNodes * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&tris, 3 * (size_t)n * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&trisRef, 3 * (size_t)n * sizeof(float4)));
+  size_t scanBytes = 0;
+  GB_TRY(rocprim::exclusive_scan(nullptr, scanBytes, subSizes, scratchOff, 0u, nS, rocprim::plus<uint32_t>(), stream));
+  GB_TRY(hipMalloc(&tmp, scanBytes ? scanBytes : 16));
+  GB_TRY(hipMemsetAsync(height, 0, sizeof(uint32_t), stream));
+  GB_TRY(hipMemcpyAsync(order, top.order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  // the top's records, float and packed (the packing of rtbvh::packNodes; part refs are patched in by k_sub_relocate)
+  std::vector<rtbvh::Node16> top16(nTop);
+  for (uint32_t i = 0; i < nTop; ++i) {
+    const rtbvh::Node& nd = top.nodes[i];
+    rtbvh::Node16& q = top16[i];
+    for (int a = 0; a < 3; ++a) {
+      q.box0[2 * a] = rtbvh::toHalfDirected(nd.lo0[a] * top.boxScale, false), q.box0[2 * a + 1] = rtbvh::toHalfDirected(nd.hi0[a] * top.boxScale, true);
+      q.box1[2 * a] = rtbvh::toHalfDirected(nd.lo1[a] * top.boxScale, false), q.box1[2 * a + 1] = rtbvh::toHalfDirected(nd.hi1[a] * top.boxScale, true);
+    }
+    for (int c = 0; c < 2; ++c) {
+      const int32_t ref = nd.child[c];
+      if (ref >= 0) q.child[c] = ref * 32;
+      else if ((~(uint32_t)ref) & rtbvh::kPartFlag) q.child[c] = 0;  // (patched)
+      else q.child[c] = (int32_t)~(((~(uint32_t)ref) >> 3) * 48u | ((~(uint32_t)ref) & 7u));
+    }
+  }
+  static_assert(sizeof(rtbvh::Node) == 4 * sizeof(float4) && sizeof(rtbvh::Node16) == 2 * sizeof(uint4), "node layouts");
+  GB_TRY(hipMemcpyAsync(nodesF, top.nodes.data(), (size_t)nTop * sizeof(rtbvh::Node), hipMemcpyHostToDevice, stream));
+  GB_TRY(hipMemcpyAsync(nodes16, top16.data(), (size_t)nTop * sizeof(rtbvh::Node16), hipMemcpyHostToDevice, stream));
+  std::vector<SubItem> hs(nSub);
+  for (uint32_t i = 0; i < nSub; ++i) hs[i] = SubItem{top.parts[i].b, top.parts[i].e, top.parts[i].depth, top.parts[i].parent, top.parts[i].slot};
+  if (nSub) GB_TRY(hipMemcpyAsync(subs, hs.data(), (size_t)nSub * sizeof(SubItem), hipMemcpyHostToDevice, stream));
+  const dim3 blk(256), grdN((n + 255) / 256);
+  hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, cb);
+  hipLaunchKernelGGL(k_tri_boxes, grdN, blk, 0, stream, dVpos, dTriShade, n, lo, hi, cb);
+  uint32_t nTotal = nTop, maxDepth = top.maxDepth;
+  if (nSub) {
+    hipLaunchKernelGGL(k_sub_sizes, dim3((nSub + 255) / 256), blk, 0, stream, subs, nSub, subSizes);
+    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subSizes, scratchOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
+    const size_t ldsBytes = subtree_lds_bytes((int)kSubMax);
+    {
+      static std::atomic<unsigned long long> ldsSet{0};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = -1;
+      if (dev < 0 || !(ldsSet.load() & (1ull << dev))) {
+        GB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_subtree<(int)kSubMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)ldsBytes));
+        if (dev >= 0) ldsSet.fetch_or(1ull << dev);
+      }
+    }
+    hipLaunchKernelGGL((k_subtree<(int)kSubMax>), dim3(nSub), dim3(kSubMax), ldsBytes, stream, subs, scratchOff, order, lo, hi, top.leafMax,
+                       top.depthCap, scratch, subNodes, height);
+    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subNodes, finalOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(k_sub_relocate, dim3(nSub), blk, 0, stream, subs, scratchOff, subNodes, finalOff, nTop, scratch, top.pad,
+                       top.boxScale, nodes16, nodesF);
+    uint32_t lastOff = 0, lastCnt = 0, h = 0;
+    GB_TRY(hipMemcpyAsync(&lastOff, finalOff + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipMemcpyAsync(&lastCnt, subNodes + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipMemcpyAsync(&h, height, 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipStreamSynchronize(stream));
+    nTotal = nTop + lastOff + lastCnt;
+    maxDepth = maxDepth > h ? maxDepth : h;
+    if (nTotal > maxNodes) {
+      cleanup();
+      return hipErrorInvalidValue;
+    }
+  }
+  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
+  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
+  GB_TRY(hipStreamSynchronize(stream));
+  GB_TRY(hipGetLastError());
+  keepOutputs = true;
+  out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;
+  out->n_nodes = nTotal, out->maxDepth = maxDepth;
+  cleanup();
+  return hipSuccess;
+}
+
 }  // namespace rtk

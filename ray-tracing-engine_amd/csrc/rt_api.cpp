@@ -422,11 +422,25 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   c->device = opt ? opt->device : 0;
   // the tree: host SAH builder, or the device builder (tiny scenes always take the host's
   // special cases)
-  const bool gpuBuild = ((opt && opt->bvh_builder == RT_BVH_DEVICE) || getenv("RT_BVH_GPU")) && sc->n_triangles >= 16;
+  // (RT_BVH_GPU=1 / =2: the device / the hybrid builder whatever the options say — the test suites run whole on either)
+  const char* gpuEnv = getenv("RT_BVH_GPU");
+  const uint32_t wantBuilder = gpuEnv ? (uint32_t)atoi(gpuEnv) : (opt ? opt->bvh_builder : (uint32_t)RT_BVH_HOST);
+  if (wantBuilder > RT_BVH_HYBRID) {
+    delete c;
+    return fail(RT_ERR_INVALID, "unknown bvh_builder %u", wantBuilder);
+  }
+  // (a scene of a single part has no top to build on the host: the device builder's own path handles it)
+  const bool hybrid = wantBuilder == RT_BVH_HYBRID && sc->n_triangles > 1024u;
+  const bool gpuBuild = (wantBuilder == RT_BVH_DEVICE || wantBuilder == RT_BVH_HYBRID) && sc->n_triangles >= 16;
+  rtbvh::TopBuilt topBuilt;
   rtbvh::ScenePlan plan;
   const auto tBuild0 = std::chrono::steady_clock::now();
   try {
-    if (gpuBuild) {
+    if (hybrid) {
+      rtbvh::buildTop(*sc, opt ? opt->bvh_leaf_max : 0, 1024u, topBuilt);
+      c->bvh.leafMax = topBuilt.leafMax, c->bvh.pad = topBuilt.pad, c->bvh.originBound = topBuilt.originBound, c->bvh.boxScale = topBuilt.boxScale;
+      c->bvh.depthCap = topBuilt.depthCap;
+    } else if (gpuBuild) {
       plan = rtbvh::planScene(*sc, opt ? opt->bvh_leaf_max : 0);
       c->bvh.leafMax = plan.leafMax, c->bvh.pad = plan.pad, c->bvh.originBound = plan.originBound, c->bvh.boxScale = plan.boxScale;
     } else if (prebuilt) {
@@ -456,7 +470,8 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   UP(vnrm, sc->vertex_nrm, (size_t)sc->n_vertices * 3);
   if (gpuBuild) {
     rtk::GpuBvh G;
-    hipError_t he = rtk::gpu_bvh_build(S.vpos, S.triShade, sc->n_triangles, plan, &G, nullptr);
+    hipError_t he = hybrid ? rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sc->n_triangles, topBuilt, &G, nullptr)
+                           : rtk::gpu_bvh_build(S.vpos, S.triShade, sc->n_triangles, plan, &G, nullptr);
     if (he != hipSuccess) {
       rt_destroy(c);
       return fail(RT_ERR_HIP, "device BVH build failed: %s", hipGetErrorString(he));
@@ -466,7 +481,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     c->dNodesF = G.nodesF;
     c->bvh.maxDepth = G.maxDepth;
     S.n_nodes = G.n_nodes;
-    c->builder = RT_BVH_DEVICE;
+    c->builder = hybrid ? RT_BVH_HYBRID : RT_BVH_DEVICE;
   } else {
     UP(nodes, c->bvh.nodes16.data(), c->bvh.nodes16.size() * 2);
     UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);
@@ -903,7 +918,7 @@ int rt_bvh_info_get(rt_ctx* c, rt_bvh_info* out) {
 
 int rt_bvh_export(rt_ctx* c, void* nodes64, void* tris48) {
   if (!c) return fail(RT_ERR_INVALID, "ctx is null");
-  if (c->builder == RT_BVH_DEVICE) {  // the arrays only exist on the device
+  if (c->builder != RT_BVH_HOST) {  // the arrays only exist on the device
     HIP_TRY(hipSetDevice(c->device));
     if (nodes64) HIP_TRY(hipMemcpy(nodes64, c->dNodesF, (size_t)c->S.n_nodes * sizeof(rtbvh::Node), hipMemcpyDeviceToHost));
     if (tris48) HIP_TRY(hipMemcpy(tris48, c->S.tris, (size_t)c->S.n_tris * sizeof(rtbvh::TriRec), hipMemcpyDeviceToHost));

@@ -125,7 +125,9 @@ np.savez(sys.argv[2], **out)
                       # without the rotation passes
                       ("host", {"RT_TEST_HOST_BUILDER": "1"}), ("host_no_size_axis", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_SIZEAXIS": "0"}),
                       ("host_size_axis_unbiased", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_SIZEBIAS": "1"}),
-                      ("host_no_rotations", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_ROT": "0"})):
+                      ("host_no_rotations", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_ROT": "0"}),
+                      # ... and the hybrid builder (RT_BVH_GPU=2 overrides the option): the host's top, exact subtrees on the device
+                      ("hybrid", {"RT_BVH_GPU": "2"})):
         out = tmp_path / (name + ".npz")
         r = subprocess.run([sys.executable, str(script), pyrt.ROOT, str(out)], env=dict(os.environ, **env), capture_output=True,
                            text=True, timeout=600)
@@ -148,7 +150,7 @@ def test_build_time_and_tree_quality_report(capsys):
     for kind, n in (("lowres", 200000), ("hires", 200000), ("stress", 200000)):
         s = pyrt.Scene(kind, 256, 256)
         out = {}
-        for name, b in (("host", pyrt.BVH_HOST), ("device", pyrt.BVH_DEVICE)):
+        for name, b in (("host", pyrt.BVH_HOST), ("device", pyrt.BVH_DEVICE), ("hybrid", pyrt.BVH_HYBRID)):
             ctx = pyrt.Context(s, bvh_builder=b)
             bi = ctx.bvh_info()
             p = pyrt.make_params(256, 256, 4, seed=2, collect_stats=1)
@@ -160,11 +162,15 @@ def test_build_time_and_tree_quality_report(capsys):
     with capsys.disabled():
         for kind, out in rows:
             print("\n%-7s host: build %8.1f ms nodes %7d depth %2d  %.2f nodes/ray %.2f tris/ray kernel %.2f ms | "
-                  "device: build %7.1f ms nodes %7d depth %2d  %.2f nodes/ray %.2f tris/ray kernel %.2f ms"
-                  % ((kind,) + out["host"] + out["device"]), end="")
+                  "device: build %7.1f ms nodes %7d depth %2d  %.2f nodes/ray %.2f tris/ray kernel %.2f ms | "
+                  "hybrid: build %7.1f ms nodes %7d depth %2d  %.2f nodes/ray %.2f tris/ray kernel %.2f ms"
+                  % ((kind,) + out["host"] + out["device"] + out["hybrid"]), end="")
         print()
     for kind, out in rows:
         assert out["device"][3] < 1.10 * out["host"][3], (kind, out)
+        # the hybrid tree has the host's own top: what is left is the host's rotation passes and the size axis of its sweeps
+        # (measured: lowres 1.000x, hires 1.001x, stress 1.037x)
+        assert out["hybrid"][3] < 1.05 * out["host"][3], (kind, out)
     stress = dict(rows)["stress"]
     if not os.environ.get("RT_BVH_GPU"):  # (the variable forces the device builder for "host" too)
-        assert stress["device"][0] < stress["host"][0]
+        assert stress["device"][0] < stress["hybrid"][0] < stress["host"][0]
