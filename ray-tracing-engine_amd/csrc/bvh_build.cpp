@@ -688,71 +688,18 @@ static void relayoutTop(std::vector<Node>& nodes, uint32_t kTop) {
     if (nd.child[0] >= 0) heap.push_back({area(nd.lo0, nd.hi0), nd.child[0]}), std::push_heap(heap.begin(), heap.end());
     if (nd.child[1] >= 0) heap.push_back({area(nd.lo1, nd.hi1), nd.child[1]}), std::push_heap(heap.begin(), heap.end());
   }
-  // the subtrees hanging below the top, largest first.  RT_BVH_TREELET = T > 1 lays each of
-  // them out in TREELETS: T nodes grown from a root by surface area (the nodes a ray that
-  // enters the root most likely visits next) get consecutive indices — T = 4 is one 128-B
-  // cache line of packed nodes — then the subtrees below the treelet follow, each the same
-  // way; T <= 1 is plain pre-order.  (Measured on the 1 M-triangle scene: see DESIGN.md.)
+  // the subtrees hanging below the top, largest first, in pre-order.  (Measured and dropped in rounds 2-3: treelets of 4 ... 512
+  // nodes grown by area, sibling pairs adjacent, breadth-first below the top — all within +-0.5 % on the 1 M-triangle scene.)
   std::sort(heap.begin(), heap.end(), [](const Item& x, const Item& y) { return y < x; });
-  static const int treelet = getenv("RT_BVH_TREELET") ? atoi(getenv("RT_BVH_TREELET")) : 0;
-  // RT_BVH_LAYOUT (experiment): 1 = depth-first over SIBLING PAIRS (the two children of a node
-  // get consecutive indices — one 64-B block —, then the pairs below child 0, then those below
-  // child 1); 2 = breadth-first below the top.
-  static const int layout = getenv("RT_BVH_LAYOUT") ? atoi(getenv("RT_BVH_LAYOUT")) : 0;
   std::vector<int32_t> st;
-  if (layout == 1) {
-    for (const Item& r : heap) newOf[r.idx] = static_cast<int32_t>(next++);  // the roots below the top, largest first
-    for (const Item& r : heap) {
-      st.push_back(r.idx);
-      while (!st.empty()) {
-        const int32_t x = st.back();
-        st.pop_back();
-        const int32_t c0 = nodes[x].child[0], c1 = nodes[x].child[1];
-        if (c0 >= 0) newOf[c0] = static_cast<int32_t>(next++);
-        if (c1 >= 0) newOf[c1] = static_cast<int32_t>(next++);
-        if (c1 >= 0) st.push_back(c1);
-        if (c0 >= 0) st.push_back(c0);
-      }
-    }
-    heap.clear();
-  } else if (layout == 2) {
-    std::vector<int32_t> q;
-    for (const Item& r : heap) q.push_back(r.idx);
-    for (size_t h = 0; h < q.size(); ++h) {
-      const int32_t x = q[h];
-      newOf[x] = static_cast<int32_t>(next++);
-      if (nodes[x].child[0] >= 0) q.push_back(nodes[x].child[0]);
-      if (nodes[x].child[1] >= 0) q.push_back(nodes[x].child[1]);
-    }
-    heap.clear();
-  }
   for (const Item& r : heap) {
     st.push_back(r.idx);
     while (!st.empty()) {
       const int32_t root = st.back();
       st.pop_back();
-      if (treelet <= 1) {
-        newOf[root] = static_cast<int32_t>(next++);
-        if (nodes[root].child[1] >= 0) st.push_back(nodes[root].child[1]);
-        if (nodes[root].child[0] >= 0) st.push_back(nodes[root].child[0]);
-        continue;
-      }
-      std::vector<Item> grow;  // max-heap of candidates to join this treelet
-      grow.push_back({1e300, root});
-      int taken = 0;
-      while (!grow.empty() && taken < treelet) {
-        std::pop_heap(grow.begin(), grow.end());
-        const Item it = grow.back();
-        grow.pop_back();
-        newOf[it.idx] = static_cast<int32_t>(next++);
-        ++taken;
-        const Node& nd = nodes[it.idx];
-        if (nd.child[0] >= 0) grow.push_back({area(nd.lo0, nd.hi0), nd.child[0]}), std::push_heap(grow.begin(), grow.end());
-        if (nd.child[1] >= 0) grow.push_back({area(nd.lo1, nd.hi1), nd.child[1]}), std::push_heap(grow.begin(), grow.end());
-      }
-      // what is left are the roots of the next treelets: nearest-in-memory = largest first
-      std::sort(grow.begin(), grow.end());  // ascending: the largest is pushed last, popped first
-      for (const Item& g : grow) st.push_back(g.idx);
+      newOf[root] = static_cast<int32_t>(next++);
+      if (nodes[root].child[1] >= 0) st.push_back(nodes[root].child[1]);
+      if (nodes[root].child[0] >= 0) st.push_back(nodes[root].child[0]);
     }
   }
   if (next != n) throw std::runtime_error("internal error: relayout lost nodes");

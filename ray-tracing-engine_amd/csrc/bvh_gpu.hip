@@ -286,204 +286,20 @@ __global__ __launch_bounds__(256) void k_level_split(const WorkItem* __restrict_
   }
 }
 
-// ---------------------------------------------------------------- binned SAH top (round 3)
-// One workgroup per range above kSubMax triangles: the host builder's binned split (bvh_build.cpp split():
-// centroid bounds, 64 bins per axis for ranges of >= 65,536 triangles, else 16; cost = area x ceil(count /
-// leafMax) per side; the first cheapest (axis, bin) that fits the depth budget) and a STABLE partition of the
-// range's triangle order — the range leaves the Morton order here, which is what the Morton-cut top could not do
-// (DESIGN.md section 6).  Outputs per range: the split position, both child boxes (exact: unions of the bins), the
-// number of children that go on as work items / become exact subtrees.
-constexpr int kTopT = 1024, kTopBins = 64;
-
-template <int T>
-__global__ __launch_bounds__(T) void k_top_split(const WorkItem* __restrict__ items, uint32_t depth, int depthCap, uint32_t leafMax,
-                                                 uint32_t subMax, uint32_t* __restrict__ order, uint32_t* __restrict__ order2,
-                                                 const float4* __restrict__ triLo, const float4* __restrict__ triHi,
-                                                 uint32_t* __restrict__ splitPos, float* __restrict__ childBoxes,
-                                                 uint32_t* __restrict__ innerCnt, uint32_t* __restrict__ subCnt, int binsSmall) {
-  __shared__ int sBin[3][kTopBins][6];       // ordered-int box of each bin (lo xyz, hi xyz)
-  __shared__ uint32_t sCnt[3][kTopBins];
-  __shared__ int sCb[6];                     // centroid bounds (ordered ints)
-  __shared__ unsigned long long sBest;
-  __shared__ uint32_t sScan[T / 64];
-  __shared__ uint32_t sBaseL, sBaseR;
-  const uint32_t w = blockIdx.x, i = threadIdx.x;
-  const uint32_t b = items[w].b, e = items[w].e, n = e - b;
-  const int NB = n < 65536u ? binsSmall : 64;
-  if (i < 3) sCb[i] = 0x7fffffff, sCb[3 + i] = (int)0x80000000;
-  for (uint32_t k = i; k < 3u * kTopBins; k += T) {
-    int* q = sBin[k / kTopBins][k % kTopBins];
-    q[0] = q[1] = q[2] = 0x7fffffff, q[3] = q[4] = q[5] = (int)0x80000000;
-    sCnt[k / kTopBins][k % kTopBins] = 0u;
-  }
-  if (i == 0) sBest = ~0ull;
-  __syncthreads();
-  // 1. centroid bounds
-  {
-    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-    for (uint32_t p = i; p < n; p += T) {
-      const uint32_t t = order[b + p];
-      const float4 l = triLo[t], h = triHi[t];
-      const float c[3] = {0.5f * l.x + 0.5f * h.x, 0.5f * l.y + 0.5f * h.y, 0.5f * l.z + 0.5f * h.z};
-      for (int a = 0; a < 3; ++a) mn[a] = min(mn[a], fkey(c[a])), mx[a] = max(mx[a], fkey(c[a]));
-    }
-    for (int a = 0; a < 3; ++a) {
-      for (int off = 32; off > 0; off >>= 1) mn[a] = min(mn[a], __shfl_xor(mn[a], off, 64)), mx[a] = max(mx[a], __shfl_xor(mx[a], off, 64));
-      if ((i & 63u) == 0) atomicMin(&sCb[a], mn[a]), atomicMax(&sCb[3 + a], mx[a]);
-    }
-  }
-  __syncthreads();
-  float cbLo[3], scale[3];
-  bool axisOk[3];
-  for (int a = 0; a < 3; ++a) {
-    cbLo[a] = funkey(sCb[a]);
-    const float ext = funkey(sCb[3 + a]) - cbLo[a];
-    axisOk[a] = ext > 0.f;
-    scale[a] = axisOk[a] ? (float)NB / ext : 0.f;
-  }
-  auto bin_of = [&](float c, int a) { return min(NB - 1, max(0, (int)((c - cbLo[a]) * scale[a]))); };
-  // 2. bins
-  for (uint32_t p = i; p < n; p += T) {
-    const uint32_t t = order[b + p];
-    const float4 l = triLo[t], h = triHi[t];
-    const float c[3] = {0.5f * l.x + 0.5f * h.x, 0.5f * l.y + 0.5f * h.y, 0.5f * l.z + 0.5f * h.z};
-    const int kl[3] = {fkey(l.x), fkey(l.y), fkey(l.z)}, kh[3] = {fkey(h.x), fkey(h.y), fkey(h.z)};
-    for (int a = 0; a < 3; ++a) {
-      if (!axisOk[a]) continue;
-      const int k = bin_of(c[a], a);
-      int* q = sBin[a][k];
-      for (int d = 0; d < 3; ++d) atomicMin(&q[d], kl[d]), atomicMax(&q[3 + d], kh[d]);
-      atomicAdd(&sCnt[a][k], 1u);
-    }
-  }
-  __syncthreads();
-  // 3. candidates: thread (axis, bin k): left = bins [0, k], right = bins (k, NB)
-  const int rem = depthCap - (int)depth - 1;
-  const unsigned long long maxSide = rem >= 31 ? ~0ull : (unsigned long long)leafMax << (rem < 0 ? 0 : rem);
-  auto area_keys = [&](const int* bx) {
-    const float dx = funkey(bx[3]) - funkey(bx[0]), dy = funkey(bx[4]) - funkey(bx[1]), dz = funkey(bx[5]) - funkey(bx[2]);
-    return dx < 0.f ? 0.f : dx * dy + dy * dz + dz * dx;
-  };
-  if (i < 3u * kTopBins) {
-    const int a = (int)i / kTopBins, k = (int)i % kTopBins;
-    if (axisOk[a] && k < NB - 1) {
-      int L[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000}, R[6];
-      for (int d = 0; d < 6; ++d) R[d] = L[d];
-      uint32_t cl = 0, cr = 0;
-      for (int j = 0; j < NB; ++j) {
-        int* dst = j <= k ? L : R;
-        for (int d = 0; d < 3; ++d) dst[d] = min(dst[d], sBin[a][j][d]), dst[3 + d] = max(dst[3 + d], sBin[a][j][3 + d]);
-        if (j <= k) cl += sCnt[a][j];
-        else cr += sCnt[a][j];
-      }
-      if (cl && cr && cl <= maxSide && cr <= maxSide) {
-        const float cost = area_keys(L) * (float)((cl + leafMax - 1u) / leafMax) + area_keys(R) * (float)((cr + leafMax - 1u) / leafMax);
-        if (cost == cost && cost >= 0.f)
-          atomicMin(&sBest, ((unsigned long long)__float_as_uint(cost) << 32) | ((unsigned long long)a << 16) | (unsigned)k);
-      }
-    }
-  }
-  __syncthreads();
-  const unsigned long long bb = sBest;
-  int ax = -1, kb = 0;
-  uint32_t cntL = n / 2u;
-  if (bb != ~0ull) {
-    ax = (int)((bb >> 16) & 3u), kb = (int)(bb & 0xffffu);
-    cntL = 0;
-    for (int j = 0; j <= kb; ++j) cntL += sCnt[ax][j];
-    // (the host builder's guard against extremely lopsided splits deep in the tree)
-    const uint32_t small = cntL < n - cntL ? cntL : n - cntL;
-    if (n > 64u && small * 64u < n && depth > (uint32_t)rtbvh::kMaxDepth / 2u) ax = -1, cntL = n / 2u;
-  }
-  // 4. stable partition of the range's order (no admissible split: the range is cut at its middle as it stands)
-  if (ax >= 0) {
-    if (i == 0) sBaseL = 0u, sBaseR = 0u;
-    __syncthreads();
-    for (uint32_t p0 = 0; p0 < n; p0 += T) {
-      const uint32_t p = p0 + i;
-      uint32_t t = 0;
-      bool left = false;
-      if (p < n) {
-        t = order[b + p];
-        const float4 l = triLo[t], h = triHi[t];
-        const float c = ax == 0 ? 0.5f * l.x + 0.5f * h.x : ax == 1 ? 0.5f * l.y + 0.5f * h.y : 0.5f * l.z + 0.5f * h.z;
-        left = bin_of(c, ax) <= kb;
-      }
-      // block-wide inclusive scan of the flags: wave scan by shuffles, then the waves' totals
-      uint32_t incl = left ? 1u : 0u;
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((int)(i & 63u) >= d) incl += o;
-      }
-      if ((i & 63u) == 63u) sScan[i >> 6] = incl;
-      __syncthreads();
-      uint32_t lefts = 0;
-      for (uint32_t k = 0; k < (uint32_t)T / 64u; ++k) {
-        const uint32_t tot = sScan[k];
-        if (k < (i >> 6)) incl += tot;
-        lefts += tot;
-      }
-      const uint32_t inChunk = min((uint32_t)T, n - p0);
-      if (p < n) {
-        if (left) order2[b + sBaseL + incl - 1u] = t;
-        else order2[b + cntL + sBaseR + (i - incl)] = t;
-      }
-      __syncthreads();
-      if (i == 0) sBaseL += lefts, sBaseR += inChunk - lefts;
-      __syncthreads();
-    }
-    for (uint32_t p = i; p < n; p += T) order[b + p] = order2[b + p];
-  }
-  // 5. the node's child boxes and what its children are
-  if (ax < 0) {
-    // boxes of the two halves of the current order
-    __syncthreads();
-    if (i < 12) reinterpret_cast<int*>(sBin[0][0])[i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;  // [0..5] left, [6..11] right
-    __syncthreads();
-    for (uint32_t p = i; p < n; p += T) {
-      const uint32_t t = order[b + p];
-      const float4 l = triLo[t], h = triHi[t];
-      int* q = reinterpret_cast<int*>(sBin[0][0]) + (p < cntL ? 0 : 6);
-      atomicMin(&q[0], fkey(l.x)), atomicMin(&q[1], fkey(l.y)), atomicMin(&q[2], fkey(l.z));
-      atomicMax(&q[3], fkey(h.x)), atomicMax(&q[4], fkey(h.y)), atomicMax(&q[5], fkey(h.z));
-    }
-    __syncthreads();
-    if (i < 12) childBoxes[12 * (size_t)w + i] = funkey(reinterpret_cast<int*>(sBin[0][0])[i]);
-  } else if (i < 12) {
-    const bool right = i >= 6;
-    const int d = (int)i % 6;
-    int v = d < 3 ? 0x7fffffff : (int)0x80000000;
-    for (int j = right ? kb + 1 : 0; j <= (right ? NB - 1 : kb); ++j) v = d < 3 ? min(v, sBin[ax][j][d]) : max(v, sBin[ax][j][d]);
-    childBoxes[12 * (size_t)w + i] = funkey(v);
-  }
-  if (i == 0) {
-    const uint32_t n0 = cntL, n1 = n - cntL;
-    splitPos[w] = b + cntL;
-    innerCnt[w] = (n0 > leafMax && n0 > subMax ? 1u : 0u) + (n1 > leafMax && n1 > subMax ? 1u : 0u);
-    subCnt[w] = (n0 > leafMax && n0 <= subMax ? 1u : 0u) + (n1 > leafMax && n1 <= subMax ? 1u : 0u);
-  }
-}
-
 // Write the node (packed + float form) and the next level's work items.
 __global__ void k_level_emit(const WorkItem* __restrict__ items, uint32_t count, uint32_t levelBase, uint32_t nextBase,
                              const uint32_t* __restrict__ splitPos, const uint32_t* __restrict__ innerOff, uint32_t leafMax,
                              const float4* __restrict__ segLo, const float4* __restrict__ segHi, uint32_t N2, float pad,
                              float boxScale, uint4* __restrict__ nodes16, float4* __restrict__ nodesF, WorkItem* __restrict__ next,
                              const uint32_t* __restrict__ subOff, uint32_t subBase, SubItem* __restrict__ subs, uint32_t subMax,
-                             uint32_t depth, const float* __restrict__ childBoxes) {
+                             uint32_t depth) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= count) return;
   const uint32_t b = items[w].b, e = items[w].e, k = splitPos[w];
   uint32_t slot = innerOff[w], sslot = subBase + subOff[w];
   int32_t child[2];
   const uint32_t cb[2] = {b, k}, ce[2] = {k, e};
-  Box3 B0, B1;
-  if (childBoxes) {  // (binned top: the boxes the split kernel accumulated)
-    const float* q = childBoxes + 12 * (size_t)w;
-    B0 = Box3{q[0], q[1], q[2], q[3], q[4], q[5]}, B1 = Box3{q[6], q[7], q[8], q[9], q[10], q[11]};
-  } else {
-    B0 = range_box(segLo, segHi, N2, b, k), B1 = range_box(segLo, segHi, N2, k, e);
-  }
+  Box3 B0 = range_box(segLo, segHi, N2, b, k), B1 = range_box(segLo, segHi, N2, k, e);
   // child 0 = the smaller box (any-hit rays of the big-scene kernels enter it first: rt_kernels.hip Trav::round)
   const bool swp = half_area(B1) < half_area(B0);
   if (swp) {
@@ -848,20 +664,15 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
   void* tmp = nullptr;
   bool keepOutputs = false;
   static const uint32_t subMax = getenv("RT_BVH_GPU_SUB") ? (uint32_t)atoi(getenv("RT_BVH_GPU_SUB")) : kSubMax;  // 0: Morton cuts all the way down
-  // the top of the tree (ranges above subMax): the cheapest cut of the static Morton order (default), or —
-  // RT_BVH_GPU_TOP=binned — the host builder's binned SAH with a stable partition per range (k_top_split).  Measured
-  // (profiles/r03_device_bvh_top_variants.txt): the binned top gives WORSE trees under exact subtrees of <= 1,024
-  // triangles (nodes per ray: lowres 10.0 vs 8.54, stress 37.7 vs 36.6; 16 / 32 / 64 bins alike) — the host builder
-  // sweeps exactly up to 4,096 triangles, and 16 bins between 1,024 and 4,096 lose more than Morton cuts do — and
-  // takes 55 instead of 19 ms for 1 M triangles, so it stays an option.
-  static const bool binnedTop = getenv("RT_BVH_GPU_TOP") && !strcmp(getenv("RT_BVH_GPU_TOP"), "binned") && subMax > 0;
-  float* childBoxes = nullptr;
-  static const int binsSmall = getenv("RT_BVH_GPU_BINS") ? atoi(getenv("RT_BVH_GPU_BINS")) : 16;  // bins per axis below 65,536 triangles (<= 64)
+  // the top of the tree (ranges above subMax): the cheapest cut of the static Morton order.  (Round 3 also had the host's
+  // binned SAH as a device kernel here: worse trees under 1,024-triangle subtrees and 3 x the time,
+  // profiles/r03_device_bvh_top_variants.txt; round 4's hybrid builder — gpu_bvh_build_over_top below — takes the host's
+  // OWN top instead.)
   auto cleanup = [&]() {
     for (void* p : {(void*)lo, (void*)hi, (void*)segLo, (void*)segHi, (void*)cb, (void*)keys, (void*)keys2, (void*)vals, (void*)order,
                     (void*)splitPos, (void*)innerCnt, (void*)innerOff, (void*)itemsA, (void*)itemsB, (void*)subs, (void*)subCnt,
                     (void*)subOff, (void*)subSizes, (void*)scratchOff, (void*)subNodes, (void*)finalOff, (void*)height, (void*)scratch,
-                    (void*)childBoxes, tmp})
+                    tmp})
       if (p) (void)hipFree(p);
     if (!keepOutputs)
       for (void* p : {(void*)nodes16, (void*)nodesF, (void*)tris, (void*)trisRef})
@@ -892,9 +703,6 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
   GB_TRY(hipMalloc((void**)&height, sizeof(uint32_t)));
   GB_TRY(hipMalloc((void**)&scratch, 4 * (size_t)maxNodes * sizeof(float4)));
   GB_TRY(hipMemsetAsync(height, 0, sizeof(uint32_t), stream));
-  // (top ranges hold more than subMax triangles each, and a level's ranges are disjoint)
-  const size_t topNodesMax = binnedTop ? (size_t)n / (subMax ? subMax : 1u) + 64u : 0u;
-  if (binnedTop) GB_TRY(hipMalloc((void**)&childBoxes, topNodesMax * 12 * sizeof(float)));
   GB_TRY(hipMalloc((void**)&nodes16, 2 * (size_t)maxNodes * sizeof(uint4)));
   GB_TRY(hipMalloc((void**)&nodesF, 4 * (size_t)maxNodes * sizeof(float4)));
   GB_TRY(hipMalloc((void**)&tris, 3 * (size_t)n * sizeof(float4)));
@@ -910,11 +718,9 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
   hipLaunchKernelGGL(k_tri_boxes, grdN, blk, 0, stream, dVpos, dTriShade, n, lo, hi, cb);
   hipLaunchKernelGGL(k_morton, grdN, blk, 0, stream, lo, hi, n, cb, keys, vals);
   GB_TRY(rocprim::radix_sort_pairs(tmp, sortBytes, keys, keys2, vals, order, n, 0, 63, stream));
-  if (!binnedTop) {
-    hipLaunchKernelGGL(k_seg_leaves, dim3((N2 + 255) / 256), blk, 0, stream, lo, hi, order, n, N2, segLo, segHi);
-    for (uint32_t cnt = N2 / 2; cnt >= 1; cnt >>= 1)  // level with `cnt` nodes starts at index cnt
-      hipLaunchKernelGGL(k_seg_level, dim3((cnt + 255) / 256), blk, 0, stream, cnt, cnt, segLo, segHi);
-  }
+  hipLaunchKernelGGL(k_seg_leaves, dim3((N2 + 255) / 256), blk, 0, stream, lo, hi, order, n, N2, segLo, segHi);
+  for (uint32_t cnt = N2 / 2; cnt >= 1; cnt >>= 1)  // level with `cnt` nodes starts at index cnt
+    hipLaunchKernelGGL(k_seg_level, dim3((cnt + 255) / 256), blk, 0, stream, cnt, cnt, segLo, segHi);
   // top-down, one level at a time; ranges of <= subMax triangles become items of the exact builder
   const WorkItem root{0u, n};
   GB_TRY(hipMemcpyAsync(itemsA, &root, sizeof root, hipMemcpyHostToDevice, stream));
@@ -930,24 +736,13 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
       cleanup();
       return hipErrorInvalidValue;  // (cannot happen: the depth budget is enforced by the split choice)
     }
-    if (binnedTop) {
-      if (count > topNodesMax) {
-        cleanup();
-        return hipErrorInvalidValue;
-      }
-      // (`vals` — the sort's input — is free by now: the partition's second buffer)
-      hipLaunchKernelGGL((k_top_split<kTopT>), dim3(count), dim3(kTopT), 0, stream, cur, depth, P.depthCap, leafMax, subMax, order, vals, lo,
-                         hi, splitPos, childBoxes, innerCnt, subCnt, binsSmall);
-    } else {
-      hipLaunchKernelGGL(k_level_split, dim3((count + 3) / 4), dim3(256), 0, stream, cur, count, depth, P.depthCap, leafMax, segLo,
-                         segHi, N2, keys2, splitPos, innerCnt, subCnt, subMax);
-    }
+    hipLaunchKernelGGL(k_level_split, dim3((count + 3) / 4), dim3(256), 0, stream, cur, count, depth, P.depthCap, leafMax, segLo,
+                       segHi, N2, keys2, splitPos, innerCnt, subCnt, subMax);
     GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, innerCnt, innerOff, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream));
     GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subCnt, subOff, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream));
     const uint32_t nextBase = levelBase + count;
     hipLaunchKernelGGL(k_level_emit, dim3((count + 255) / 256), blk, 0, stream, cur, count, levelBase, nextBase, splitPos, innerOff,
-                       leafMax, segLo, segHi, N2, P.pad, P.boxScale, nodes16, nodesF, nxt, subOff, nSub, subs, subMax, depth,
-                       binnedTop ? childBoxes : (const float*)nullptr);
+                       leafMax, segLo, segHi, N2, P.pad, P.boxScale, nodes16, nodesF, nxt, subOff, nSub, subs, subMax, depth);
     uint32_t lastOff = 0, lastCnt = 0, lastSubOff = 0, lastSubCnt = 0;
     GB_TRY(hipMemcpyAsync(&lastOff, innerOff + (count - 1), 4, hipMemcpyDeviceToHost, stream));
     GB_TRY(hipMemcpyAsync(&lastCnt, innerCnt + (count - 1), 4, hipMemcpyDeviceToHost, stream));

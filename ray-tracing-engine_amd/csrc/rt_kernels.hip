@@ -1722,9 +1722,8 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   const uint32_t rows = A.stackLevels + (PHOTON ? 2 * A.k : 0);
   const size_t ldsBytes = 4u * ((rows < 4u ? 4u : rows) * BLOCK + (POOLED ? VP_WORDS : 0));
   RenderArgs A1 = A;
-  static const int tpbEnv = getenv("RT_TILES_PER_BLOCK") ? atoi(getenv("RT_TILES_PER_BLOCK")) : 0;
-  A1.tilesPerBlock = tpbEnv > 0 ? (uint32_t)tpbEnv : 1u;
-  const uint32_t nBlocks = (blocks + A1.tilesPerBlock - 1u) / A1.tilesPerBlock;
+  A1.tilesPerBlock = 1u;  // (more wave tiles per workgroup unbalance the grid: C3 13.7 / 14.8 / 17.8 ms at 4 / 8 / 16 in round 3)
+  const uint32_t nBlocks = blocks;
   // Occupancy target (waves per SIMD) of the one-wave-per-workgroup kernels.
   constexpr int MINW = PHOTON ? 2 : 4;
   if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, true, 1>), dim3(nBlocks), dim3(BLOCK), ldsBytes, stream, S, A1, accum, counters);

@@ -95,8 +95,8 @@ def test_frames_on_device_built_tree_vs_oracle(kind, w, h, spp):
 
 def test_device_builder_variants_are_exact(tmp_path):
     """The builders' other configurations (environment knobs, read once per process): Morton cuts all the
-    way down (RT_BVH_GPU_SUB=0, round 2's tree), exact subtrees of <= 64 triangles, and the binned-SAH top
-    (RT_BVH_GPU_TOP=binned: k_top_split).  Every one must give the exhaustive loop's hits and the default tree's frame."""
+    way down (RT_BVH_GPU_SUB=0, round 2's tree), exact subtrees of <= 64 triangles, the host builder's variants and the
+    hybrid builder.  Every one must give the exhaustive loop's hits and the default tree's frame."""
     import subprocess
     import sys
     script = tmp_path / "v.py"
@@ -120,7 +120,6 @@ np.savez(sys.argv[2], **out)
 ''')
     runs = {}
     for name, env in (("default", {}), ("morton_all_the_way", {"RT_BVH_GPU_SUB": "0"}), ("subtrees_64", {"RT_BVH_GPU_SUB": "64"}),
-                      ("binned_top", {"RT_BVH_GPU_TOP": "binned"}), ("binned_top_64_bins", {"RT_BVH_GPU_TOP": "binned", "RT_BVH_GPU_BINS": "64"}),
                       # ... and the host builder's: its default, without the size axis, with an unbiased size axis,
                       # without the rotation passes
                       ("host", {"RT_TEST_HOST_BUILDER": "1"}), ("host_no_size_axis", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_SIZEAXIS": "0"}),
