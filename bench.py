@@ -418,13 +418,13 @@ def main():
     # counters: this run's, or (fallback) a committed profile of the SAME device code
     khash = kernel_source_hash()
     if pmc is None:
-        ppath = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % args.workload)
+        ppath = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % args.workload)
         if os.path.exists(ppath) and not args.spp and world == 1 and args.accel == "bvh":
             saved = json.load(open(ppath))
             if saved.get("kernel_source_hash") == khash:
-                pmc, pmc_source = saved["counters"], "profiles/r03_pmc_%s.json @ kernel hash %s [%s]" % (args.workload, khash, pmc_source)
+                pmc, pmc_source = saved["counters"], "profiles/r04_pmc_%s.json @ kernel hash %s [%s]" % (args.workload, khash, pmc_source)
             else:
-                pmc_source = "profiles/r03_pmc_%s.json is for kernel hash %s, this build is %s: not used [%s]" % (
+                pmc_source = "profiles/r04_pmc_%s.json is for kernel hash %s, this build is %s: not used [%s]" % (
                     args.workload, saved.get("kernel_source_hash"), khash, pmc_source)
     hbm_bytes = valu = lane_util = None
     if pmc:
@@ -479,8 +479,11 @@ def main():
             "lanes_at_leaf_per_node_step": st.reserved[2] / max(st.reserved[0], 1),
             "lanes_without_ray_per_node_step": st.reserved[3] / max(st.reserved[0], 1),
             "note": ("HBM-side reading: measured FETCH/WRITE bytes; a scene below 256 MB is partly served by the Infinity "
-                     "Cache, whose hits these fabric-side counters still count.  What BINDS this traversal is roofline.vector_l1: "
-                     "the CU's vector L1 at its measured ceiling for divergent 16-B requests" if args.workload in HBM_BOUND else
+                     "Cache, whose hits these fabric-side counters still count.  roofline.vector_l1 (the CU's vector L1 against its "
+                     "measured ceiling for divergent 16-B requests) is the unit nearest its limit, but round 4's one-request node "
+                     "records showed it does not bind alone: 29 % fewer L1 accesses, the same wait cycles, an 18 % longer frame "
+                     "(+64 % VALU).  What bounds a wave's traversal step is the memory latency of its slowest lane plus its own "
+                     "instruction issue, at the 16 waves per CU that 128 VGPRs and the LDS stacks allow" if args.workload in HBM_BOUND else
                      "cache-resident scene: the binding unit is VALU issue under divergence, not any bandwidth; "
                      "frac = SQ_INSTS_VALU / s over 1024 SIMDs x 2.4 GHz / 2"),
         })
@@ -497,7 +500,7 @@ def main():
             "config": {"workload": "%s: %s scene (%d triangles), %dx%d, -m %d -N %d, pixel RNG seed 1, %s"
                                    % (args.workload, kind, scene.desc.n_triangles, w, h, mode, spp,
                                       args.accel + (", wavefront integrator" if args.integrator == "wavefront" else "")),
-                       "parallelism": "tiles32x%d, owned tiles gathered to rank 0" % world,
+                       "parallelism": "tiles32x%d, owned tiles sent to rank 0" % world,
                        "exchange": exchange, "assemble_ms": assemble_ms,
                        "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_ms_min_over_ranks": kernel_ms_min,
                        "rays_per_frame": rays_per_frame, "samples_per_frame": tot[4],

@@ -321,9 +321,10 @@ __global__ void k_photon_gather(const float4* __restrict__ items, const float4* 
 // The tree's EXPLICIT topology, for the k-NN walk (rt_kernels.hip knn_query).  The reference's tree is implicit in the
 // array order (kdtree.h:60-69: the node of a range [b, e) is its median element b + (e - b) / 2, the halves are its
 // children, the axis cycles with the depth), and a walk that carries (b, e, depth) spends a third of its instructions on
-// range and level arithmetic.  One record per photon instead: {left child | axis << 30, right child, the PARENT's split
-// coordinate (float bits), the parent's axis}; no child = KD_NONE.  The parent's split lets a far child that waited on
-// the walk's stack be re-tested against kdtree.h:105 (dx * dx >= m_bestdist) from its own record when it is popped.
+// range and level arithmetic.  One 32-byte record per photon instead (one cache line, two requests): {position x, y, z,
+// left child | axis << 30}{right child, the PARENT's split coordinate (float bits), the parent's axis, 0}; no child =
+// KD_NONE.  The parent's split lets a far child that waited on the walk's stack be re-tested against kdtree.h:105
+// (dx * dx >= m_bestdist) from its own record when it is popped.
 __global__ void k_kd_topology(const float4* __restrict__ phPos, uint32_t n, uint4* __restrict__ topo) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -343,7 +344,9 @@ __global__ void k_kd_topology(const float4* __restrict__ phPos, uint32_t n, uint
     const float4 pp = phPos[parent];
     psplit = __float_as_uint(paxis == 0 ? pp.x : paxis == 1 ? pp.y : pp.z);
   }
-  topo[i] = make_uint4(left | ((level % 3) << 30), right, psplit, paxis);
+  const float4 me = phPos[i];
+  topo[2 * (size_t)i] = make_uint4(__float_as_uint(me.x), __float_as_uint(me.y), __float_as_uint(me.z), left | ((level % 3) << 30));
+  topo[2 * (size_t)i + 1] = make_uint4(right, psplit, paxis, 0u);
 }
 
 hipError_t launch_kd_topology(const float4* phPos, uint32_t n, uint4* topo, hipStream_t stream) {

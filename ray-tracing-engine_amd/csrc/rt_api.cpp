@@ -687,7 +687,7 @@ int rt_set_photons(rt_ctx* c, const float* pos3, const float* dir3, uint32_t n) 
   int rc = upload(&c->phPos, p.data(), n);
   if (rc == RT_OK) rc = upload(&c->phDir, d.data(), n);
   if (rc == RT_OK && n) {  // the arrays come in tree order (kdtree.h:60-69): the explicit topology follows from it
-    hipError_t he = hipMalloc(reinterpret_cast<void**>(&c->phTopo), (size_t)n * sizeof(uint4));
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&c->phTopo), 2 * (size_t)n * sizeof(uint4));
     if (he == hipSuccess) he = rtk::launch_kd_topology(c->phPos, n, c->phTopo, nullptr);
     if (he == hipSuccess) he = hipDeviceSynchronize();
     if (he != hipSuccess) rc = fail(RT_ERR_HIP, "photon topology failed: %s", hipGetErrorString(he));
@@ -1264,7 +1264,7 @@ int rt_build_photon_map(rt_ctx* c, uint32_t n_requested, uint32_t seed, uint32_t
     he = rtk::launch_kd_build(items, m, -1, nullptr);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phPos), m * sizeof(float4));
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phDir), m * sizeof(float4));
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phTopo), m * sizeof(uint4));
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&phTopo), 2 * (size_t)m * sizeof(uint4));
     if (he == hipSuccess) he = rtk::launch_photon_gather(items, slotDir, m, phPos, phDir, nullptr, nullptr);
     if (he == hipSuccess) he = rtk::launch_kd_topology(phPos, m, phTopo, nullptr);
   }

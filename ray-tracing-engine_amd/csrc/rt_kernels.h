@@ -46,7 +46,7 @@ struct DevScene {
   const uint32_t* meshVtxBegin;
   const float4* phPos;     // photons in kd-tree order: xyz + pad
   const float4* phDir;     // income direction xyz + weight
-  const uint4* phTopo;     // per photon: {left child | axis << 30, right child, parent's split coordinate, parent's axis} (kd_build.hip k_kd_topology)
+  const uint4* phTopo;     // per photon, 32 B: {position xyz, left child | axis << 30}{right child, parent's split coordinate, parent's axis, 0} (kd_build.hip k_kd_topology)
   uint32_t n_tris, n_nodes, n_lights, n_photons;
   float invBoxScale;       // 1 / rtbvh::Built::boxScale
   uint32_t topK;           // node records [0, topK) are LDS-resident in the persistent kernel (set per launch)

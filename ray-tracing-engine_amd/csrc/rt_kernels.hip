@@ -635,8 +635,10 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, uint32_
   uint32_t cur = S.n_photons / 2u;  // the root: the median of [0, n)
   bool popped = false;
   while (cur != KD_NONE) {
-    const float4 P = S.phPos[cur];
-    const uint4 T = S.phTopo[cur];
+    // the node's record: {position, left | axis << 30}{right, parent's split, parent's axis, -}: both halves in one line
+    const uint4 ra = S.phTopo[2 * (size_t)cur], rb = S.phTopo[2 * (size_t)cur + 1];
+    const float4 P = make_float4(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z), 0.f);
+    const uint4 T = make_uint4(ra.w, rb.x, rb.y, rb.z);
     bool go = true;
     if (popped) {  // kdtree.h:105 for the activation that left this child behind, and the geometric prune
       const float pc = T.w == 0u ? p.x : T.w == 1u ? p.y : p.z;

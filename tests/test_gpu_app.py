@@ -118,7 +118,7 @@ def test_bench_spawns_its_own_launcher(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["config"]["rays_per_frame"] == 5526901 and d["value"] > 0
-    assert "owned tiles gathered" in d["config"]["parallelism"]
+    assert "owned tiles sent" in d["config"]["parallelism"]
     # the N > 1 line is complete and attributable — a per-rank roofline measured by
     # rank 0's own PMC child passes on its shard, the CPU baseline, and where the frame time goes
     roof, cfg = d["roofline"], d["config"]

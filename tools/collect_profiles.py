@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the round's measurement summaries from gpurun_out/round/ into profiles/ (tracked),
 and write profiles/<round>_pmc_<WL>.json — the counters bench.py falls back to (marked as such,
-and only for the same kernel sources) when rocprofv3 cannot run.  usage: collect_profiles.py r03"""
+and only for the same kernel sources) when rocprofv3 cannot run.  usage: collect_profiles.py r04"""
 import json
 import os
 import shutil
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "round")
 dst = os.path.join(ROOT, "profiles")
 for wl in ("C1", "C2", "C3", "C4", "C5", "C5x8"):
@@ -34,7 +34,8 @@ for name, to in (("c2_kernel_stats.csv", R + "_c2_kernel_stats.csv"), ("c2_pmc_s
                  ("bench_C2_under_rocprof.json", R + "_bench_C2_under_rocprof.json"), ("bench_C2_tuned.json", R + "_bench_C2_tuned.json"),
                  ("c2_pmc_ta.txt", R + "_c2_pmc_ta.txt"), ("c5_pmc_ta.txt", R + "_c5_pmc_ta.txt"),
                  ("c2_pmc_issue.txt", R + "_c2_pmc_issue.txt"), ("c5x8_pmc_spp8.txt", R + "_c5x8_pmc_spp8.txt"),
-                 ("c3_pmc.txt", R + "_c3_pmc.txt"), ("gather_microbench.json", R + "_gather_microbench.json")):
+                 ("c3_pmc.txt", R + "_c3_pmc.txt"), ("c3_pmc_issue.txt", R + "_c3_pmc_issue.txt"), ("c3_pmc_ta.txt", R + "_c3_pmc_ta.txt"),
+                 ("kernel_resources.txt", R + "_kernel_resources.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, to))

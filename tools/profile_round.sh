@@ -3,7 +3,7 @@
 # with its own in-run rocprofv3 PMC passes), rocprofv3 kernel stats of the default bench
 # command, the wide PMC sets of C2 / C3 / C5, section clocks of the pooled kernel, the builders'
 # report, the gather microbenchmark (the vector L1's divergent request ceiling).  Output:
-# gpurun_out/round/ (copy the summaries to profiles/ with `tools/collect_profiles.py r03`).
+# gpurun_out/round/ (copy the summaries to profiles/ with `tools/collect_profiles.py r04`).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/round; mkdir -p $out
@@ -25,9 +25,11 @@ tools/pmc.sh c3 --workload C3 > /dev/null 2>&1; cp gpurun_out/pmc_c3/summary.txt
 tools/pmc_ta.sh c2 --workload C2 --spp 16 > $out/c2_pmc_ta.txt 2>&1
 tools/pmc_ta.sh c5 --workload C5 --spp 32 > $out/c5_pmc_ta.txt 2>&1
 tools/pmc_issue.sh c2 --workload C2 --spp 16 > $out/c2_pmc_issue.txt 2>&1
+tools/pmc_issue.sh c3 --workload C3 > $out/c3_pmc_issue.txt 2>&1
+tools/pmc_ta.sh c3 --workload C3 > $out/c3_pmc_ta.txt 2>&1
 echo "pmc done"
 tools/phase_timing.sh C2 C4 C5 > $out/phase.log 2>&1; for w in C2 C4 C5; do [ -s gpurun_out/phase_$w.json ] && cp gpurun_out/phase_$w.json $out/; done
 echo "phase done"
 python3 -m pytest tests/test_gpu_bvhbuild.py tests/test_gpu_kdbuild.py -m gpu -q -s -k "report or built_on_the_device" > $out/builders.txt 2>&1
-ray-tracing-engine_amd/bin/gather_bench > $out/gather_microbench.json 2>&1
+tools/kernel_resources.sh > $out/kernel_resources.txt 2>&1
 echo "all done"
