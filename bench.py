@@ -164,6 +164,27 @@ def tune_tree(ctx, pyrt, args, mode, nph):
 
 
 # ----------------------------------------------------------------------------- CPU baseline
+def effective_cores():
+    """Cores this process can actually keep busy: the affinity mask, capped by the cgroup's CPU quota (a GPU box of this pool
+    shows 256 hardware threads and grants its one-GPU share, 16 cores' worth: 128 OpenMP threads then scale 13.5 x, not 128 x)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    eff = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return eff, n, quota
+
+
 def cpu_baseline(ctx, scene_kind, mode, device, full=False):
     """The REAL reference (oracle/_ref/ref_harness = reference sources + our driver), timed
     single-threaded on a bounded sample of the same scene and mode (96x96, 8 spp, ~10 s:
@@ -198,27 +219,38 @@ def cpu_baseline(ctx, scene_kind, mode, device, full=False):
     out["port_bvh_value"] = (sb.rays_closest + sb.rays_shadow) / t_bvh / 1e6
     out["port_bvh_sample"] = "%s scene, 256x256, -m %d -N 8 (BASELINE config 1's size), oracle CPU BVH, 1 thread" % (scene_kind, mode)
     # all host cores (pixel RNG mode: independent pixels, OpenMP over runs of 64 pixels; the reference itself cannot run
-    # multi-threaded: one global RNG).  The samples are sized for the host: a 512 x 512 frame is 4,096 work items
-    # (>= 16 per thread on a 256-thread box) and the spp is chosen for about 4 s at half-linear scaling, so every thread
-    # has work for the whole measurement; the thread count OpenMP actually used comes back from the oracle.
-    threads = len(os.sched_getaffinity(0))
+    # multi-threaded: one global RNG).  "All cores" = the cores this process may use: the affinity mask capped by the
+    # cgroup's CPU quota (effective_cores).  The samples are sized for them: a 512 x 512 frame is 4,096 work items (>= 16 per
+    # thread on a 256-thread box) and the spp is chosen for about 4 s at half-linear scaling, so every thread has work for the
+    # whole measurement; the thread count OpenMP actually used comes back from the oracle.
+    threads, hw_threads, quota = effective_cores()
     per_sample = rays / float(w * h * n)
     big_w = 512
 
     def all_cores(rate1, accel):
-        want = max(1.0, rate1 * 1e6 * 0.5 * threads * 4.0)
-        spp = int(min(64, max(1, round(want / (big_w * big_w * per_sample)))))
+        # a one-spp probe frame first: the usable share of the host is not always visible (a CPU quota may be enforced outside
+        # this process' cgroup files), so the sample is sized from the rate the probe actually reaches, for about 4 s
         sc = pyrt.Scene(scene_kind, big_w, big_w)
+        probe_spp = 1
+        t0 = time.perf_counter()
+        _, _, sp = orc.render(sc, pyrt.make_params(big_w, big_w, probe_spp, mode=mode, rng_mode=pyrt.RNG_PIXEL), math_mode=orc.MATH_DET,
+                              threads=threads, accel=accel)
+        probe_rate = (sp.rays_closest + sp.rays_shadow) / max(time.perf_counter() - t0, 1e-6)
+        spp = int(min(64, max(1, round(probe_rate * 4.0 / (big_w * big_w * per_sample)))))
         pa = pyrt.make_params(big_w, big_w, spp, mode=mode, rng_mode=pyrt.RNG_PIXEL)
         t0 = time.perf_counter()
-        _, _, sa = orc.render(sc, pa, math_mode=orc.MATH_DET, threads=0, accel=accel)
+        _, _, sa = orc.render(sc, pa, math_mode=orc.MATH_DET, threads=threads, accel=accel)
         dt = time.perf_counter() - t0
         return (sa.rays_closest + sa.rays_shadow) / dt / 1e6, int(sa.reserved[0]), "%dx%dx%d spp, %.1f s" % (big_w, big_w, spp, dt)
 
     out["port_loop_all_cores_value"], used1, out["port_loop_all_cores_sample"] = all_cores(out["port_loop_value"], orc.ACCEL_LOOP)
     out["port_bvh_all_cores_value"], used2, out["port_bvh_all_cores_sample"] = all_cores(out["port_bvh_value"], orc.ACCEL_OBVH)
     out["all_cores_threads"] = min(used1, used2)
-    out["all_cores_threads_available"] = threads
+    out["all_cores_threads_available"] = hw_threads
+    out["cpu_quota_cores"] = quota  # (cgroup CPU quota of this process if one is visible; None = none visible)
+    # what the host really gave: the all-cores rate over the one-thread rate of the same code
+    out["all_cores_speedup_loop"] = out["port_loop_all_cores_value"] / out["port_loop_value"]
+    out["all_cores_speedup_bvh"] = out["port_bvh_all_cores_value"] / out["port_bvh_value"]
     # the GPU's exhaustive kernel (the reference algorithm itself on the GPU), bounded frame
     try:
         gp = pyrt.make_params(512, 512, 8, mode=mode, seed=1, accel=pyrt.ACCEL_BRUTE)
