@@ -9,6 +9,7 @@
 #include <cstring>
 #include <exception>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -40,15 +41,94 @@ struct Prim {
   uint32_t id;
 };
 
-constexpr uint32_t kSweepMax = 4096;  // 32768 built a slightly worse C4 tree (10.3 vs 10.0 nodes/ray)
+// The primitive arrays without value-initialisation: a std::vector would zero 44 MB per million triangles on ONE thread (page
+// faults included) before the threads that fill it get to touch it.
+struct PrimBuf {
+  std::unique_ptr<Prim[]> p;
+  size_t n = 0;
+  void resize(size_t k) { p.reset(new Prim[k]), n = k; }
+  size_t size() const { return n; }
+  Prim* begin() { return p.get(); }
+  const Prim* begin() const { return p.get(); }
+  Prim& operator[](size_t i) { return p[i]; }
+  const Prim& operator[](size_t i) const { return p[i]; }
+};
+
+constexpr uint32_t kSweepMax = 4096;
+TriRec makeRec(const rt_scene_desc& sc, uint32_t t, uint32_t mesh);  // 32768 built a slightly worse C4 tree (10.3 vs 10.0 nodes/ray)
 
 struct Builder {
   const rt_scene_desc& sc;
-  std::vector<Prim> prims;
+  PrimBuf prims;
   Built& out;
   uint32_t leafMax;
   int depthCap = kMaxDepth - 1;  // deepest leaf level the tree may use
   uint32_t grain = ~0u;          // ranges above this many primitives fork a thread
+  // threads a SINGLE big split may use for its passes over the range (the top levels of a big scene are otherwise one
+  // thread walking a million primitives four times per level: 47 of the hybrid builder's 64 host milliseconds)
+  uint32_t parThreads = 1;
+  PrimBuf scratch;  // the parallel partition's second buffer (ranges are disjoint: concurrent splits do not collide)
+  static constexpr uint32_t kParSplit = 131072u;
+  // f(thread, begin, end) over contiguous chunks of [b, e); the chunking — hence any result that is merged in chunk
+  // order — does not depend on how many threads actually ran
+  template <class F>
+  void parChunks(uint32_t b, uint32_t e, F f) const {
+    const uint32_t T = std::max<uint32_t>(1u, std::min<uint32_t>(parThreads, (e - b) / 32768u));
+    if (T <= 1u) {
+      f(0u, b, e);
+      return;
+    }
+    const uint64_t n = e - b;
+    std::vector<std::thread> th;
+    th.reserve(T - 1u);
+    for (uint32_t t = 1; t < T; ++t) th.emplace_back([&f, b, n, t, T] { f(t, b + (uint32_t)(n * t / T), b + (uint32_t)(n * (t + 1) / T)); });
+    f(0u, b, b + (uint32_t)(n / T));
+    for (std::thread& x : th) x.join();
+  }
+  // primitives (boxes, centroids, size keys) of every triangle, validated; optionally the reference-order records
+  float loadPrims(TriRec* trisRef) {
+    prims.resize(sc.n_triangles);
+    float maxAbs = 0.f;
+    for (uint32_t m = 0; m < sc.n_meshes; ++m) {
+      if (sc.mesh_tri_begin[m] > sc.mesh_tri_begin[m + 1]) throw std::runtime_error("mesh_tri_begin not monotone");
+      std::vector<float> mx(64, 0.f);
+      std::vector<int> bad(64, 0);
+      parChunks(sc.mesh_tri_begin[m], sc.mesh_tri_begin[m + 1], [&](uint32_t th, uint32_t tb, uint32_t te) {
+        float localMax = 0.f;
+        for (uint32_t t = tb; t < te; ++t) {
+          Prim& p = prims[t];
+          p.id = t;
+          p.box.reset();
+          for (int k = 0; k < 3; ++k) {
+            const uint32_t v = sc.tri_vtx[3 * static_cast<size_t>(t) + k];
+            if (v < sc.mesh_vtx_begin[m] || v >= sc.mesh_vtx_begin[m + 1]) {
+              bad[th] = 1;
+              return;
+            }
+            const float* q = sc.vertex_pos + 3 * static_cast<size_t>(v);
+            for (int a = 0; a < 3; ++a) {
+              if (!std::isfinite(q[a])) {
+                bad[th] = 2;
+                return;
+              }
+              localMax = std::max(localMax, std::fabs(q[a]));
+            }
+            p.box.grow(q);
+          }
+          for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+          p.c[3] = -std::log2(std::max({p.box.hi[0] - p.box.lo[0], p.box.hi[1] - p.box.lo[1], p.box.hi[2] - p.box.lo[2], 1e-30f}));
+          if (trisRef) trisRef[t] = makeRec(sc, t, m);
+        }
+        mx[th] = localMax;
+      });
+      for (int t = 0; t < 64; ++t) {
+        if (bad[t] == 1) throw std::runtime_error("triangle references a vertex outside its mesh");
+        if (bad[t] == 2) throw std::runtime_error("non-finite vertex position");
+        maxAbs = std::max(maxAbs, mx[t]);
+      }
+    }
+    return maxAbs;
+  }
   // buildTop: ranges of at most this many primitives are not split here (0 = build the whole tree)
   uint32_t cutoff = 0;
   std::vector<TopBuilt::Part> parts;
@@ -74,9 +154,25 @@ struct Builder {
   uint32_t split(uint32_t b, uint32_t e, int depth) {
     const uint32_t n = e - b;
     const uint32_t median = b + n / 2;
+    const bool par = parThreads > 1u && n >= kParSplit;
     Box cb;
     cb.reset();
-    for (uint32_t i = b; i < e; ++i) cb.grow(prims[i].c);
+    float sLo = std::numeric_limits<float>::infinity(), sHi = -sLo;
+    if (par) {  // one pass, every thread its chunk: centroid bounds and the size keys' range
+      Box cbt[64];
+      float lo4[64], hi4[64];
+      for (int t = 0; t < 64; ++t) cbt[t].reset(), lo4[t] = sLo, hi4[t] = sHi;
+      parChunks(b, e, [&](uint32_t t, uint32_t cb0, uint32_t ce0) {
+        Box x;
+        x.reset();
+        float l = std::numeric_limits<float>::infinity(), h = -l;
+        for (uint32_t i = cb0; i < ce0; ++i) x.grow(prims[i].c), l = std::min(l, prims[i].c[3]), h = std::max(h, prims[i].c[3]);
+        cbt[t] = x, lo4[t] = l, hi4[t] = h;
+      });
+      for (int t = 0; t < 64; ++t) cb.grow(cbt[t]), sLo = std::min(sLo, lo4[t]), sHi = std::max(sHi, hi4[t]);
+    } else {
+      for (uint32_t i = b; i < e; ++i) cb.grow(prims[i].c);
+    }
     // The size axis: candidates "the k largest primitives | the rest".  A wall quad among a mesh's triangles has its
     // centroid somewhere in the middle of the room, and every centroid split leaves it in a box with half the mesh;
     // sorted by size it comes off first (the device builder's size classes, bvh_gpu.hip, had found the same thing).
@@ -89,8 +185,7 @@ struct Builder {
     static const float sizeBias = getenv("RT_BVH_SIZEBIAS") ? (float)atof(getenv("RT_BVH_SIZEBIAS")) : 1.5f;
     const bool sizeAxis = (sizeAxisMode & (n <= kSweepMax ? 1 : 2)) != 0;
     const int nAxes = sizeAxis ? 4 : 3;
-    float sLo = std::numeric_limits<float>::infinity(), sHi = -sLo;
-    if (sizeAxis)
+    if (sizeAxis && !par)
       for (uint32_t i = b; i < e; ++i) sLo = std::min(sLo, prims[i].c[3]), sHi = std::max(sHi, prims[i].c[3]);
     int axisOrder[3] = {0, 1, 2};
     std::sort(axisOrder, axisOrder + 3, [&](int x, int y) { return cb.hi[x] - cb.lo[x] > cb.hi[y] - cb.lo[y]; });
@@ -106,35 +201,45 @@ struct Builder {
     const int rem = depthCap - depth - 1;
     const uint64_t maxSide = rem >= 31 ? ~0ull : (uint64_t)leafMax << (rem < 0 ? 0 : rem);
 
-    // small ranges: exact SAH sweep over all three axes (every split position)
+    // small ranges: exact SAH sweep over all three axes (every split position).  The orders are sorted as 12-byte (key,
+    // id, position) triples, not as 44-byte primitives (the host build spends most of its time in these sorts); the
+    // comparator is a total order (ids are unique), so the arrangement is the one sorting the primitives gave.
     if (n <= kSweepMax) {
+      struct KI {
+        float key;
+        uint32_t id, pos;
+      };
       float bestCostS = std::numeric_limits<float>::infinity();
       int bestAx = -1;
       uint32_t bestPos = 0;
       std::vector<float> rightArea(n);
+      std::vector<KI> ki(n), bestOrder;
       for (int ax = 0; ax < nAxes; ++ax) {
         if (ax == 3 && !(sHi > sLo)) continue;
-        std::sort(prims.begin() + b, prims.begin() + e,
-                  [ax](const Prim& p, const Prim& q) { return p.c[ax] < q.c[ax] || (p.c[ax] == q.c[ax] && p.id < q.id); });
+        for (uint32_t i = 0; i < n; ++i) ki[i] = KI{prims[b + i].c[ax], prims[b + i].id, i};
+        std::sort(ki.begin(), ki.end(), [](const KI& p, const KI& q) { return p.key < q.key || (p.key == q.key && p.id < q.id); });
         Box acc;
         acc.reset();
         for (uint32_t i = n; i-- > 1;) {
-          acc.grow(prims[b + i].box);
+          acc.grow(prims[b + ki[i].pos].box);
           rightArea[i] = acc.halfArea();
         }
         acc.reset();
+        bool better = false;
         for (uint32_t i = 1; i < n; ++i) {
-          acc.grow(prims[b + i - 1].box);
+          acc.grow(prims[b + ki[i - 1].pos].box);
           float cost = acc.halfArea() * std::ceil(i / static_cast<float>(leafMax)) +
                        rightArea[i] * std::ceil((n - i) / static_cast<float>(leafMax));
           if (ax == 3) cost *= sizeBias;
-          if (cost < bestCostS && i <= maxSide && n - i <= maxSide) bestCostS = cost, bestAx = ax, bestPos = i;
+          if (cost < bestCostS && i <= maxSide && n - i <= maxSide) bestCostS = cost, bestAx = ax, bestPos = i, better = true;
         }
+        if (better) bestOrder = ki;
       }
       if (bestAx < 0) return medianSplit();
-      const int ax = bestAx;
-      std::sort(prims.begin() + b, prims.begin() + e,
-                [ax](const Prim& p, const Prim& q) { return p.c[ax] < q.c[ax] || (p.c[ax] == q.c[ax] && p.id < q.id); });
+      // the range in the best axis' order
+      std::vector<Prim> tmp(n);
+      for (uint32_t i = 0; i < n; ++i) tmp[i] = prims[b + bestOrder[i].pos];
+      std::copy(tmp.begin(), tmp.end(), prims.begin() + b);
       return b + bestPos;
     }
 
@@ -150,17 +255,57 @@ struct Builder {
     const int NB = (int)n < nbSplit ? 16 : nbEnv >= 2 && nbEnv <= NBMAX ? nbEnv : 64;
     float bestCost = std::numeric_limits<float>::infinity();
     int bestAxis = -1, bestBin = -1;
+    // (big ranges: the bins of all axes in ONE pass, every thread its chunk, merged — min / max and counts: the same bins
+    // whatever the chunking)
+    struct AxisBins {
+      Box bb[NBMAX];
+      uint32_t cnt[NBMAX];
+    };
+    std::vector<AxisBins> pbins;
+    if (par) {
+      float axLo4[4], scale4[4];
+      bool use4[4];
+      for (int ax = 0; ax < 4; ++ax) {
+        axLo4[ax] = ax < 3 ? cb.lo[ax] : sLo;
+        const float ext = ax < 3 ? cb.hi[ax] - cb.lo[ax] : sHi - sLo;
+        use4[ax] = ax < nAxes && ext > 0.f;
+        scale4[ax] = use4[ax] ? NB / ext : 0.f;
+      }
+      const uint32_t T = std::max<uint32_t>(1u, std::min<uint32_t>(parThreads, n / 32768u));
+      std::vector<AxisBins> tb((size_t)T * 4u);
+      for (AxisBins& x : tb)
+        for (int k = 0; k < NB; ++k) x.bb[k].reset(), x.cnt[k] = 0;
+      parChunks(b, e, [&](uint32_t t, uint32_t cb0, uint32_t ce0) {
+        AxisBins* mine = &tb[(size_t)t * 4u];
+        for (uint32_t i = cb0; i < ce0; ++i)
+          for (int ax = 0; ax < 4; ++ax) {
+            if (!use4[ax]) continue;
+            const int k = std::min(NB - 1, std::max(0, static_cast<int>((prims[i].c[ax] - axLo4[ax]) * scale4[ax])));
+            mine[ax].bb[k].grow(prims[i].box), ++mine[ax].cnt[k];
+          }
+      });
+      pbins.resize(4);
+      for (int ax = 0; ax < 4; ++ax)
+        for (int k = 0; k < NB; ++k) {
+          pbins[ax].bb[k].reset(), pbins[ax].cnt[k] = 0;
+          for (uint32_t t = 0; t < T; ++t) pbins[ax].bb[k].grow(tb[(size_t)t * 4u + ax].bb[k]), pbins[ax].cnt[k] += tb[(size_t)t * 4u + ax].cnt[k];
+        }
+    }
     for (int ax = 0; ax < nAxes; ++ax) {
       const float axLo = ax < 3 ? cb.lo[ax] : sLo;
       const float ext = ax < 3 ? cb.hi[ax] - cb.lo[ax] : sHi - sLo;
       if (!(ext > 0.f)) continue;
-      Box bb[NBMAX];
-      uint32_t cnt[NBMAX] = {0};
-      for (int k = 0; k < NB; ++k) bb[k].reset();
+      Box bbLocal[NBMAX];
+      uint32_t cntLocal[NBMAX] = {0};
+      Box* bb = par ? pbins[ax].bb : bbLocal;
+      uint32_t* cnt = par ? pbins[ax].cnt : cntLocal;
       const float scale = NB / ext;
-      for (uint32_t i = b; i < e; ++i) {
-        int k = std::min(NB - 1, std::max(0, static_cast<int>((prims[i].c[ax] - axLo) * scale)));
-        bb[k].grow(prims[i].box), ++cnt[k];
+      if (!par) {
+        for (int k = 0; k < NB; ++k) bb[k].reset();
+        for (uint32_t i = b; i < e; ++i) {
+          int k = std::min(NB - 1, std::max(0, static_cast<int>((prims[i].c[ax] - axLo) * scale)));
+          bb[k].grow(prims[i].box), ++cnt[k];
+        }
       }
       float rightArea[NBMAX];
       uint32_t rightCnt[NBMAX];
@@ -186,11 +331,39 @@ struct Builder {
     const float ext = bestAxis < 3 ? cb.hi[bestAxis] - cb.lo[bestAxis] : sHi - sLo;
     const float scale = NB / ext, lo = bestAxis < 3 ? cb.lo[bestAxis] : sLo;
     const int ax = bestAxis, bin = bestBin;
-    auto mid = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim& p) {
+    auto goesLeft = [&](const Prim& p) {
       int k = std::min(NB - 1, std::max(0, static_cast<int>((p.c[ax] - lo) * scale)));
       return k <= bin;
-    });
-    uint32_t m = static_cast<uint32_t>(mid - prims.begin());
+    };
+    uint32_t m;
+    if (par && scratch.size() == prims.size()) {
+      // stable partition through the second buffer: count per chunk, place, copy back — three passes shared by the threads
+      uint32_t nl[65] = {0};
+      parChunks(b, e, [&](uint32_t t, uint32_t cb0, uint32_t ce0) {
+        uint32_t c = 0;
+        for (uint32_t i = cb0; i < ce0; ++i) c += goesLeft(prims[i]) ? 1u : 0u;
+        nl[t + 1] = c;
+      });
+      uint32_t chunkB[65] = {0};
+      {
+        const uint32_t T = std::max<uint32_t>(1u, std::min<uint32_t>(parThreads, n / 32768u));
+        for (uint32_t t = 0; t <= T; ++t) chunkB[t] = T <= 1u ? (t ? e : b) : b + (uint32_t)((uint64_t)n * t / T);
+        for (uint32_t t = 0; t < 64; ++t) nl[t + 1] += nl[t];
+        m = b + nl[T];
+      }
+      parChunks(b, e, [&](uint32_t t, uint32_t cb0, uint32_t ce0) {
+        uint32_t l = b + nl[t], r = m + (cb0 - b) - nl[t];  // (rights before this chunk: elements before it minus lefts before it)
+        for (uint32_t i = cb0; i < ce0; ++i) {
+          if (goesLeft(prims[i])) scratch[l++] = prims[i];
+          else scratch[r++] = prims[i];
+        }
+      });
+      parChunks(b, e, [&](uint32_t, uint32_t cb0, uint32_t ce0) { std::copy(scratch.begin() + cb0, scratch.begin() + ce0, prims.begin() + cb0); });
+      (void)chunkB;
+    } else {
+      auto mid = std::partition(prims.begin() + b, prims.begin() + e, goesLeft);
+      m = static_cast<uint32_t>(mid - prims.begin());
+    }
     if (m == b || m == e) return medianSplit();
     // keep the tree shallow: refuse extremely lopsided SAH splits on big ranges
     const uint32_t small = std::min(m - b, e - m);
@@ -1130,34 +1303,19 @@ void buildTop(const rt_scene_desc& sc, uint32_t leafMax, uint32_t cutoff, TopBui
   if (sc.n_triangles == 0 || sc.n_triangles >= (1u << 28)) throw std::runtime_error("triangle count out of range");
   if (sc.mesh_tri_begin[sc.n_meshes] != sc.n_triangles || sc.mesh_vtx_begin[sc.n_meshes] != sc.n_vertices)
     throw std::runtime_error("mesh offset tables inconsistent with counts");
+  const auto tTop0 = std::chrono::steady_clock::now();
+  auto msSince = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tTop0).count(); };
   Built scratch;  // (the Builder writes triangle records and the plan's numbers here; only the numbers are kept)
   scratch.leafMax = leafMax;
   Builder B(sc, scratch, leafMax);
   B.cutoff = cutoff;
   const char* slack = getenv("RT_BVH_SLACK");
   B.depthCap = std::min(kMaxDepth - 1, B.levelsFor(sc.n_triangles) + (slack ? atoi(slack) : defaultDepthSlack(B.levelsFor(sc.n_triangles))));
-  B.prims.resize(sc.n_triangles);
-  float maxAbs = 0.f;
-  for (uint32_t m = 0; m < sc.n_meshes; ++m) {
-    if (sc.mesh_tri_begin[m] > sc.mesh_tri_begin[m + 1]) throw std::runtime_error("mesh_tri_begin not monotone");
-    for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; ++t) {
-      Prim& p = B.prims[t];
-      p.id = t;
-      p.box.reset();
-      for (int k = 0; k < 3; ++k) {
-        const uint32_t v = sc.tri_vtx[3 * static_cast<size_t>(t) + k];
-        if (v < sc.mesh_vtx_begin[m] || v >= sc.mesh_vtx_begin[m + 1]) throw std::runtime_error("triangle references a vertex outside its mesh");
-        const float* q = sc.vertex_pos + 3 * static_cast<size_t>(v);
-        for (int a = 0; a < 3; ++a) {
-          if (!std::isfinite(q[a])) throw std::runtime_error("non-finite vertex position");
-          maxAbs = std::max(maxAbs, std::fabs(q[a]));
-        }
-        p.box.grow(q);
-      }
-      for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
-      p.c[3] = -std::log2(std::max({p.box.hi[0] - p.box.lo[0], p.box.hi[1] - p.box.lo[1], p.box.hi[2] - p.box.lo[2], 1e-30f}));
-    }
-  }
+  uint32_t nthreads = threads ? threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("RT_BVH_THREADS")) nthreads = std::max(1, atoi(e));
+  B.parThreads = std::min(nthreads, 64u);
+  const float maxAbs = B.loadPrims(nullptr);
+  if (B.parThreads > 1u && sc.n_triangles >= Builder::kParSplit) B.scratch.resize(sc.n_triangles);
   float padRef = std::max(1.f, maxAbs);
   for (int a = 0; a < 3; ++a)
     if (std::isfinite(sc.camera.position[a])) padRef = std::max(padRef, std::fabs(sc.camera.position[a]));
@@ -1165,13 +1323,13 @@ void buildTop(const rt_scene_desc& sc, uint32_t leafMax, uint32_t cutoff, TopBui
     for (int a = 0; a < 3; ++a)
       if (std::isfinite(sc.lights[l].position[a])) padRef = std::max(padRef, std::fabs(sc.lights[l].position[a]));
   scratch.pad = 6e-5f * padRef;  // (recurse pads the boxes with it)
-  uint32_t nthreads = threads ? threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  if (const char* e = getenv("RT_BVH_THREADS")) nthreads = std::max(1, atoi(e));
   B.grain = nthreads > 1 ? std::max<uint32_t>(8192u, sc.n_triangles / (4u * nthreads)) : ~0u;
   if (sc.n_triangles <= cutoff) throw std::runtime_error("buildTop: the scene is a single part");
+  const double tPrims = msSince();
   Box root;
   Builder::Sub top;
   B.recurse(0, sc.n_triangles, 0, root, top);
+  const double tSplit = msSince();
   out.nodes.swap(top.nodes);
   smallerChildFirst(out.nodes);
   relayoutTop(out.nodes, kTopNodes);
@@ -1198,6 +1356,8 @@ void buildTop(const rt_scene_desc& sc, uint32_t leafMax, uint32_t cutoff, TopBui
   int e = 0;
   std::frexp(32768.f / std::max(maxAbs + out.pad, 1e-30f), &e);
   out.boxScale = std::ldexp(1.f, std::min(std::max(e - 1, -100), 100));
+  if (getenv("RT_BVH_VERBOSE"))
+    fprintf(stderr, "buildTop: primitives %.1f ms, splits %.1f ms, numbering %.1f ms (%u threads)\n", tPrims, tSplit - tPrims, msSince() - tSplit, nthreads);
 }
 
 void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threads) {
@@ -1217,31 +1377,13 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   // (bvh_build.h defaultDepthSlack: 3; deep trees 2 plus the levels that do not cost a wave)
   const int defSlack = defaultDepthSlack(B.levelsFor(sc.n_triangles));
   B.depthCap = std::min(kMaxDepth - 1, B.levelsFor(sc.n_triangles) + (slack ? atoi(slack) : defSlack));
-  B.prims.resize(sc.n_triangles);
+  // threads: 0 = one per hardware thread (at most 16).  The top 6 levels fork; a single big split shares its passes.
+  uint32_t nthreads = threads ? threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("RT_BVH_THREADS")) nthreads = std::max(1, atoi(e));
+  B.parThreads = std::min(nthreads, 64u);
   out.trisRef.resize(sc.n_triangles);
-  float maxAbs = 0.f;
-  for (uint32_t m = 0; m < sc.n_meshes; ++m) {
-    if (sc.mesh_tri_begin[m] > sc.mesh_tri_begin[m + 1]) throw std::runtime_error("mesh_tri_begin not monotone");
-    for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; ++t) {
-      Prim& p = B.prims[t];
-      p.id = t;
-      p.box.reset();
-      for (int k = 0; k < 3; ++k) {
-        const uint32_t v = sc.tri_vtx[3 * static_cast<size_t>(t) + k];
-        if (v < sc.mesh_vtx_begin[m] || v >= sc.mesh_vtx_begin[m + 1])
-          throw std::runtime_error("triangle references a vertex outside its mesh");
-        const float* q = sc.vertex_pos + 3 * static_cast<size_t>(v);
-        for (int a = 0; a < 3; ++a) {
-          if (!std::isfinite(q[a])) throw std::runtime_error("non-finite vertex position");
-          maxAbs = std::max(maxAbs, std::fabs(q[a]));
-        }
-        p.box.grow(q);
-      }
-      for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
-      p.c[3] = -std::log2(std::max({p.box.hi[0] - p.box.lo[0], p.box.hi[1] - p.box.lo[1], p.box.hi[2] - p.box.lo[2], 1e-30f}));
-      out.trisRef[t] = makeRec(sc, t, m);
-    }
-  }
+  const float maxAbs = B.loadPrims(out.trisRef.data());
+  if (B.parThreads > 1u && sc.n_triangles >= Builder::kParSplit) B.scratch.resize(sc.n_triangles);
   // The padding must dominate the float triangle test's own error, which grows with the
   // distance of the ray ORIGIN from the geometry (tvec = o - p0 rounds to ulp(|o|)): the
   // origins the integrator uses are the camera, the lights (photon emission) and surface
@@ -1256,9 +1398,6 @@ void build(const rt_scene_desc& sc, uint32_t leafMax, Built& out, uint32_t threa
   out.pad = 6e-5f * padRef;
   out.originBound = 16.f * padRef;
 
-  // threads: 0 = one per hardware thread (at most 16).  The top 6 levels fork.
-  uint32_t nthreads = threads ? threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  if (const char* e = getenv("RT_BVH_THREADS")) nthreads = std::max(1, atoi(e));
   B.grain = nthreads > 1 ? std::max<uint32_t>(8192u, sc.n_triangles / (4u * nthreads)) : ~0u;
 
   Box root;

@@ -35,6 +35,7 @@
 
 #include <atomic>
 
+#include <cstdio>
 #include <cstring>  // (rocPRIM's headers use memset without including it)
 #include <vector>
 
@@ -632,6 +633,229 @@ __global__ void k_sub_sizes(const SubItem* __restrict__ items, uint32_t n, uint3
   if (i < n) sizes[i] = items[i].e - items[i].b - 1u;  // a binary tree over m triangles has at most m - 1 inner nodes
 }
 
+// ---------------------------------------------------------------- tree rotations on the device (round 4)
+// bvh_build.cpp's Rotator as kernels: at every inner node N with children (L, R), swapping R with a child of L (and the
+// mirror cases), or a child of L with a child of R, is applied when it shrinks the summed surface area of the boxes —
+// children before parents, never pushing a subtree below the depth cap.  The recursion becomes one launch per DEPTH,
+// bottom-up: the nodes of one depth have disjoint subtrees and a rotation only touches its node, the node's two children
+// and their child slots, so they are independent; moved subtrees change depth only BELOW the rotated node, which the
+// levels still to come never look at (they read child records and heights).  Per pass: parents -> depths -> heights ->
+// rotations; afterwards every record is re-packed (child 0 = the smaller box again).
+using RNode = rtbvh::Node;  // 64 B: lo0 hi0 lo1 hi1 child[2] pad[2] — the layout of nodesF
+
+__global__ void k_rot_parents(const RNode* __restrict__ nodes, uint32_t n, uint32_t* __restrict__ parent) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0) parent[0] = ~0u;
+  for (int c = 0; c < 2; ++c)
+    if (nodes[i].child[c] >= 0) parent[nodes[i].child[c]] = i;
+}
+__global__ void k_rot_depths(const uint32_t* __restrict__ parent, uint32_t n, uint8_t* __restrict__ depth, uint32_t* __restrict__ maxDepth) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t d = 0;
+  for (uint32_t a = parent[i]; a != ~0u && d < 64u; a = parent[a]) ++d;
+  depth[i] = (uint8_t)d;
+  atomicMax(maxDepth, d);
+}
+__device__ __forceinline__ int rot_height(const uint8_t* height, int32_t ref) { return ref < 0 ? 0 : (int)height[ref]; }
+__global__ void k_rot_heights(const RNode* __restrict__ nodes, uint32_t n, const uint8_t* __restrict__ depth, uint32_t d,
+                              uint8_t* __restrict__ height) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || depth[i] != d) return;
+  height[i] = (uint8_t)(1 + max(rot_height(height, nodes[i].child[0]), rot_height(height, nodes[i].child[1])));
+}
+__device__ __forceinline__ Box3 rot_child(const RNode& n, int i) {
+  return i ? Box3{n.lo1[0], n.lo1[1], n.lo1[2], n.hi1[0], n.hi1[1], n.hi1[2]} : Box3{n.lo0[0], n.lo0[1], n.lo0[2], n.hi0[0], n.hi0[1], n.hi0[2]};
+}
+__device__ __forceinline__ void rot_set(RNode& n, int i, int32_t ref, const Box3& b) {
+  if (i) n.lo1[0] = b.lx, n.lo1[1] = b.ly, n.lo1[2] = b.lz, n.hi1[0] = b.hx, n.hi1[1] = b.hy, n.hi1[2] = b.hz;
+  else n.lo0[0] = b.lx, n.lo0[1] = b.ly, n.lo0[2] = b.lz, n.hi0[0] = b.hx, n.hi0[1] = b.hy, n.hi0[2] = b.hz;
+  n.child[i] = ref;
+}
+__device__ __forceinline__ Box3 rot_union(const Box3& a, const Box3& b) {
+  return Box3{fminf(a.lx, b.lx), fminf(a.ly, b.ly), fminf(a.lz, b.lz), fmaxf(a.hx, b.hx), fmaxf(a.hy, b.hy), fmaxf(a.hz, b.hz)};
+}
+__global__ void k_rot_level(RNode* __restrict__ nodes, uint32_t n, const uint8_t* __restrict__ depth, uint32_t d, int depthCap,
+                            uint8_t* __restrict__ height, uint32_t* __restrict__ swaps) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n || depth[idx] != d) return;
+  RNode N = nodes[idx];
+  float bestDelta = -1e-7f * (half_area(rot_child(N, 0)) + half_area(rot_child(N, 1)));
+  int bestS = -1, bestG = -1;
+  for (int s = 0; s < 2; ++s) {
+    const int32_t l = N.child[s], r = N.child[1 - s];
+    if (l < 0) continue;
+    if ((int)d + 2 + rot_height(height, r) > depthCap) continue;  // r would sit one level deeper
+    const Box3 rb = rot_child(N, 1 - s);
+    const float oldArea = half_area(rot_child(N, s));
+    const RNode L = nodes[l];
+    for (int g = 0; g < 2; ++g) {  // grandchild g goes up, its sibling stays with r
+      const float delta = half_area(rot_union(rot_child(L, 1 - g), rb)) - oldArea;
+      if (delta < bestDelta) bestDelta = delta, bestS = s, bestG = g;
+    }
+  }
+  int bestX = -1;
+  if (N.child[0] >= 0 && N.child[1] >= 0) {  // grandchild <-> grandchild across the two sides (no depth change)
+    const RNode L = nodes[N.child[0]], R = nodes[N.child[1]];
+    const float oldArea = half_area(rot_child(N, 0)) + half_area(rot_child(N, 1));
+    for (int x = 0; x < 2; ++x) {  // L.child[0] swaps with R.child[x]
+      const Box3 lb = rot_union(rot_child(R, x), rot_child(L, 1)), rb = rot_union(rot_child(L, 0), rot_child(R, 1 - x));
+      const float delta = half_area(lb) + half_area(rb) - oldArea;
+      if (delta < bestDelta) bestDelta = delta, bestX = x, bestS = -1;
+    }
+  }
+  if (bestX >= 0) {
+    const int32_t li = N.child[0], ri = N.child[1];
+    RNode L = nodes[li], R = nodes[ri];
+    const Box3 a0 = rot_child(L, 0), bx = rot_child(R, bestX);
+    const int32_t ra = L.child[0], rb = R.child[bestX];
+    rot_set(L, 0, rb, bx);
+    rot_set(R, bestX, ra, a0);
+    rot_set(N, 0, li, rot_union(rot_child(L, 0), rot_child(L, 1)));
+    rot_set(N, 1, ri, rot_union(rot_child(R, 0), rot_child(R, 1)));
+    nodes[li] = L, nodes[ri] = R;
+    height[li] = (uint8_t)(1 + max(rot_height(height, L.child[0]), rot_height(height, L.child[1])));
+    height[ri] = (uint8_t)(1 + max(rot_height(height, R.child[0]), rot_height(height, R.child[1])));
+    atomicAdd(swaps, 1u);
+  } else if (bestS >= 0) {
+    const int sidx = bestS, g = bestG;
+    const int32_t l = N.child[sidx], r = N.child[1 - sidx];
+    RNode L = nodes[l];
+    const Box3 rb = rot_child(N, 1 - sidx), gb = rot_child(L, g);
+    const int32_t gref = L.child[g];
+    rot_set(L, g, r, rb);
+    rot_set(N, 1 - sidx, gref, gb);
+    rot_set(N, sidx, l, rot_union(rot_child(L, 0), rot_child(L, 1)));
+    nodes[l] = L;
+    height[l] = (uint8_t)(1 + max(rot_height(height, L.child[0]), rot_height(height, L.child[1])));
+    atomicAdd(swaps, 1u);
+  }
+  nodes[idx] = N;
+  height[idx] = (uint8_t)(1 + max(rot_height(height, N.child[0]), rot_height(height, N.child[1])));
+}
+// float records -> packed records (child 0 = the smaller box: any-hit rays of the big-scene kernels enter it first)
+__global__ void k_rot_pack(RNode* __restrict__ nodes, uint32_t n, float boxScale, uint4* __restrict__ nodes16) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  RNode N = nodes[i];
+  Box3 B0 = rot_child(N, 0), B1 = rot_child(N, 1);
+  if (half_area(B1) < half_area(B0)) {
+    const Box3 t = B0;
+    B0 = B1, B1 = t;
+    const int32_t c0 = N.child[0];
+    N.child[0] = N.child[1], N.child[1] = c0;
+    rot_set(N, 0, N.child[0], B0), rot_set(N, 1, N.child[1], B1);
+    nodes[i] = N;
+  }
+  const float s = boxScale;
+  const uint32_t h[12] = {half_directed(B0.lx * s, false), half_directed(B0.hx * s, true), half_directed(B0.ly * s, false),
+                          half_directed(B0.hy * s, true),  half_directed(B0.lz * s, false), half_directed(B0.hz * s, true),
+                          half_directed(B1.lx * s, false), half_directed(B1.hx * s, true), half_directed(B1.ly * s, false),
+                          half_directed(B1.hy * s, true),  half_directed(B1.lz * s, false), half_directed(B1.hz * s, true)};
+  nodes16[2 * (size_t)i + 0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+  nodes16[2 * (size_t)i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, packed_ref(N.child[0]), packed_ref(N.child[1]));
+}
+
+// Pre-order renumbering after the rotations (what the host builder's relayout leaves below its top, and what the
+// traversal's locality was tuned on): subtree sizes bottom-up, new indices top-down — a node's first inner child follows
+// it, the second follows the first one's subtree —, then a scatter with the refs rewritten.
+__global__ void k_rot_sizes(const RNode* __restrict__ nodes, uint32_t n, const uint8_t* __restrict__ depth, uint32_t d,
+                            uint32_t* __restrict__ size) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || depth[i] != d) return;
+  const int32_t c0 = nodes[i].child[0], c1 = nodes[i].child[1];
+  size[i] = 1u + (c0 >= 0 ? size[c0] : 0u) + (c1 >= 0 ? size[c1] : 0u);
+}
+__global__ void k_rot_number(const RNode* __restrict__ nodes, uint32_t n, const uint8_t* __restrict__ depth, uint32_t d,
+                             const uint32_t* __restrict__ size, uint32_t* __restrict__ newIdx) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || depth[i] != d) return;
+  if (d == 0u) newIdx[i] = 0u;
+  const uint32_t me = newIdx[i];
+  const int32_t c0 = nodes[i].child[0], c1 = nodes[i].child[1];
+  if (c0 >= 0) newIdx[c0] = me + 1u;
+  if (c1 >= 0) newIdx[c1] = me + 1u + (c0 >= 0 ? size[c0] : 0u);
+}
+__global__ void k_rot_scatter(const RNode* __restrict__ nodes, uint32_t n, const uint32_t* __restrict__ newIdx, RNode* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  RNode N = nodes[i];
+  for (int c = 0; c < 2; ++c)
+    if (N.child[c] >= 0) N.child[c] = (int32_t)newIdx[N.child[c]];
+  out[newIdx[i]] = N;
+}
+
+// `passes` rotation passes over the n float records at nodesF (0 = none), then the packed records; *maxDepthOut = the deepest
+// leaf level afterwards.  RT_BVH_GPU_ROT overrides the pass count.
+static hipError_t rotate_and_pack(float4* nodesF, uint4* nodes16, uint32_t n, int depthCap, float boxScale, int passes,
+                                  uint32_t* maxDepthOut, hipStream_t stream) {
+  static const int rotEnv = getenv("RT_BVH_GPU_ROT") ? atoi(getenv("RT_BVH_GPU_ROT")) : -1;
+  if (rotEnv >= 0) passes = rotEnv;
+  if (passes <= 0 || n < 2) return hipSuccess;
+  RNode* nodes = reinterpret_cast<RNode*>(nodesF);
+  uint32_t *parent = nullptr, *scal = nullptr;  // scal: [0] max depth, [1] swaps
+  uint8_t *depth = nullptr, *height = nullptr;
+  hipError_t e = hipMalloc((void**)&parent, (size_t)n * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&scal, 2 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&depth, n);
+  if (e == hipSuccess) e = hipMalloc((void**)&height, n);
+  const dim3 blk(256), grd((n + 255) / 256);
+  uint32_t rootHeight = 0;
+  for (int p = 0; p < passes && e == hipSuccess; ++p) {
+    e = hipMemsetAsync(scal, 0, 2 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) break;
+    hipLaunchKernelGGL(k_rot_parents, grd, blk, 0, stream, nodes, n, parent);
+    hipLaunchKernelGGL(k_rot_depths, grd, blk, 0, stream, parent, n, depth, scal);
+    uint32_t h2[2] = {0, 0};
+    e = hipMemcpyAsync(h2, scal, sizeof h2, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) break;
+    const uint32_t maxD = h2[0];
+    for (int d = (int)maxD; d >= 0; --d) hipLaunchKernelGGL(k_rot_heights, grd, blk, 0, stream, nodes, n, depth, (uint32_t)d, height);
+    for (int d = (int)maxD; d >= 0; --d) hipLaunchKernelGGL(k_rot_level, grd, blk, 0, stream, nodes, n, depth, (uint32_t)d, depthCap, height, scal + 1);
+    uint8_t rh = 0;
+    e = hipMemcpyAsync(h2, scal, sizeof h2, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&rh, height, 1, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    rootHeight = rh;
+    if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "device rotation pass %d: %u swaps, tree depth %u\n", p, h2[1], rootHeight);
+    if (e == hipSuccess && h2[1] == 0) break;
+  }
+  static const bool preorder = !getenv("RT_BVH_GPU_PREORDER") || atoi(getenv("RT_BVH_GPU_PREORDER")) != 0;
+  RNode* tmpNodes = nullptr;
+  uint32_t* size = nullptr;
+  if (e == hipSuccess && preorder) {
+    e = hipMalloc((void**)&tmpNodes, (size_t)n * sizeof(RNode));
+    if (e == hipSuccess) e = hipMalloc((void**)&size, (size_t)n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(scal, 0, 2 * sizeof(uint32_t), stream);
+    uint32_t h2[2] = {0, 0};
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_rot_parents, grd, blk, 0, stream, nodes, n, parent);
+      hipLaunchKernelGGL(k_rot_depths, grd, blk, 0, stream, parent, n, depth, scal);
+      e = hipMemcpyAsync(h2, scal, sizeof h2, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    if (e == hipSuccess) {
+      const int maxD = (int)h2[0];
+      uint32_t* newIdx = parent;  // (the parents are not needed any more)
+      for (int d = maxD; d >= 0; --d) hipLaunchKernelGGL(k_rot_sizes, grd, blk, 0, stream, nodes, n, depth, (uint32_t)d, size);
+      for (int d = 0; d <= maxD; ++d) hipLaunchKernelGGL(k_rot_number, grd, blk, 0, stream, nodes, n, depth, (uint32_t)d, size, newIdx);
+      hipLaunchKernelGGL(k_rot_scatter, grd, blk, 0, stream, nodes, n, newIdx, tmpNodes);
+      e = hipMemcpyAsync(nodes, tmpNodes, (size_t)n * sizeof(RNode), hipMemcpyDeviceToDevice, stream);
+    }
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_rot_pack, grd, blk, 0, stream, nodes, n, boxScale, nodes16);
+    e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipGetLastError();
+  }
+  for (void* q : {(void*)parent, (void*)scal, (void*)depth, (void*)height, (void*)tmpNodes, (void*)size})
+    if (q) (void)hipFree(q);
+  if (e == hipSuccess && rootHeight && maxDepthOut) *maxDepthOut = rootHeight;
+  return e;
+}
+
 #define GB_TRY(expr)            \
   do {                          \
     hipError_t e_ = (expr);     \
@@ -793,6 +1017,8 @@ hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n,
       return hipErrorInvalidValue;
     }
   }
+  // rotation passes over the whole tree (as the host builder's: 3 on big scenes, 8 on small ones)
+  GB_TRY(rotate_and_pack(nodesF, nodes16, nTotal, P.depthCap, P.boxScale, n > 200000u ? 3 : 8, &maxDepth, stream));
   // triangle records in the FINAL leaf order (the exact builder has reordered its ranges), and in reference order
   hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
   hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
@@ -910,6 +1136,7 @@ hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, ui
       return hipErrorInvalidValue;
     }
   }
+  GB_TRY(rotate_and_pack(nodesF, nodes16, nTotal, top.depthCap, top.boxScale, n > 200000u ? 3 : 8, &maxDepth, stream));
   hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
   hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
   GB_TRY(hipStreamSynchronize(stream));

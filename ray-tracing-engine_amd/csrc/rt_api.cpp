@@ -422,13 +422,17 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   c->device = opt ? opt->device : 0;
   // the tree: host SAH builder, or the device builder (tiny scenes always take the host's
   // special cases)
-  // (RT_BVH_GPU=1 / =2: the device / the hybrid builder whatever the options say — the test suites run whole on either)
+  // (RT_BVH_GPU=1 / 2 / 3: the device / hybrid / host builder whatever the options say — the test suites run whole on each)
   const char* gpuEnv = getenv("RT_BVH_GPU");
-  const uint32_t wantBuilder = gpuEnv ? (uint32_t)atoi(gpuEnv) : (opt ? opt->bvh_builder : (uint32_t)RT_BVH_HOST);
-  if (wantBuilder > RT_BVH_HYBRID) {
+  uint32_t wantBuilder = gpuEnv ? (uint32_t)atoi(gpuEnv) : (opt ? opt->bvh_builder : (uint32_t)RT_BVH_AUTO);
+  if (wantBuilder > RT_BVH_HOST) {
     delete c;
     return fail(RT_ERR_INVALID, "unknown bvh_builder %u", wantBuilder);
   }
+  // AUTO: the hybrid builder gives the host builder's tree (same node visits, same frame time: profiles/r04_builders.txt)
+  // 2-3 x sooner, so big scenes take it; trees that fit the LDS-resident top keep the host builder, whose node ORDER (most
+  // visited first) that top is cut from, and a group of contexts shares one host-built tree
+  if (wantBuilder == RT_BVH_AUTO) wantBuilder = (sc->n_triangles >= 131072u && !prebuilt) ? (uint32_t)RT_BVH_HYBRID : (uint32_t)RT_BVH_HOST;
   // (a scene of a single part has no top to build on the host: the device builder's own path handles it)
   const bool hybrid = wantBuilder == RT_BVH_HYBRID && sc->n_triangles > 1024u;
   const bool gpuBuild = (wantBuilder == RT_BVH_DEVICE || wantBuilder == RT_BVH_HYBRID) && sc->n_triangles >= 16;
@@ -438,6 +442,9 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   try {
     if (hybrid) {
       rtbvh::buildTop(*sc, opt ? opt->bvh_leaf_max : 0, 1024u, topBuilt);
+      if (getenv("RT_BVH_VERBOSE"))
+        fprintf(stderr, "hybrid builder: host top of %zu nodes over %zu parts in %.1f ms\n", topBuilt.nodes.size(), topBuilt.parts.size(),
+                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count());
       c->bvh.leafMax = topBuilt.leafMax, c->bvh.pad = topBuilt.pad, c->bvh.originBound = topBuilt.originBound, c->bvh.boxScale = topBuilt.boxScale;
       c->bvh.depthCap = topBuilt.depthCap;
     } else if (gpuBuild) {

@@ -19,7 +19,7 @@ RT_OK = 0
 MODE_RAY, MODE_PATH = 0, 1
 RNG_LEGACY, RNG_PIXEL = 0, 1
 ACCEL_BVH, ACCEL_BRUTE = 0, 1
-BVH_HOST, BVH_DEVICE, BVH_HYBRID = 0, 1, 2
+BVH_AUTO, BVH_DEVICE, BVH_HYBRID, BVH_HOST = 0, 1, 2, 3
 TRACE_CLOSEST, TRACE_ANY = 0, 1
 (UNIT_ASIN, UNIT_SINF, UNIT_COSF, UNIT_STREAM_SEED, UNIT_TRIANGLE, UNIT_BSDF, UNIT_RAY_AT, UNIT_LIGHT_EVAL,
  UNIT_SAMPLERS, UNIT_LIGHT_SAMPLE, UNIT_POW, UNIT_RECIP) = range(12)
