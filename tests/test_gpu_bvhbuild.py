@@ -25,10 +25,11 @@ def test_device_built_tree_is_exact(kind, n_loop, n_bvh):
     s = pyrt.Scene(kind, 256, 256)
     ctx = pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE)
     bi = ctx.bvh_info()
-    if kind == "cubes":
-        assert bi.builder == pyrt.BVH_DEVICE or s.desc.n_triangles < 16
+    want = int(os.environ.get("RT_BVH_GPU", pyrt.BVH_DEVICE))  # (the variable overrides the option: the suite runs under each builder)
+    if kind == "cubes":  # (34 triangles: a single part — the hybrid builder hands such a scene to the device builder's own path)
+        assert bi.builder in (want, pyrt.BVH_DEVICE) or s.desc.n_triangles < 16
     else:
-        assert bi.builder == pyrt.BVH_DEVICE
+        assert bi.builder == want
     rays = ray_batch(s, n_loop, 4321)
     ref = orc.trace(s, rays)
     h = ctx.trace(rays, pyrt.ACCEL_BVH)

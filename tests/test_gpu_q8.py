@@ -14,6 +14,9 @@ import pyrt
 from raybatch import ray_batch
 
 pytestmark = pytest.mark.gpu
+# (RT_NODES / RT_BVH_GPU override the options of every context — the whole suite is run under each form, tools/r4_suite_forms.sh;
+# the tests that hold two forms against each other need both)
+two_forms = pytest.mark.skipif(bool(os.environ.get("RT_NODES")), reason="RT_NODES forces one node format on every context")
 
 
 def bits(a):
@@ -36,6 +39,7 @@ def test_q8_hits_equal_the_exhaustive_loop_and_the_oracle(kind, n, n_orc):
     ctx.close()
 
 
+@two_forms
 @pytest.mark.parametrize("kind,w,h,spp,mode", [("cubes", 64, 64, 4, 1), ("lowres", 48, 40, 6, 1), ("hires", 96, 64, 4, 1), ("stress", 64, 48, 3, 1),
                                               ("hires", 48, 48, 16, 0), ("stress", 40, 40, 2, 0)])
 def test_q8_frames_equal_the_oracle_and_the_f16_frames(kind, w, h, spp, mode):
@@ -97,7 +101,7 @@ def test_q8_over_a_device_built_tree(kind):
     s = pyrt.Scene(kind, 64, 64)
     ctx = pyrt.Context(s, bvh_builder=pyrt.BVH_DEVICE, node_format=pyrt.NODES_Q8)
     bi = ctx.bvh_info()
-    assert bi.builder == pyrt.BVH_DEVICE and bi.node_format == pyrt.NODES_Q8
+    assert bi.builder == int(os.environ.get("RT_BVH_GPU", pyrt.BVH_DEVICE)) and bi.node_format == pyrt.NODES_Q8
     rays = ray_batch(s, 100000, 3)
     want = ctx.trace(rays, pyrt.ACCEL_BRUTE)
     assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BVH).view(np.uint8), want.view(np.uint8))
@@ -109,6 +113,7 @@ def test_q8_over_a_device_built_tree(kind):
     ctx.close(), host.close()
 
 
+@two_forms
 def test_q8_refuses_what_it_cannot_express():
     s = pyrt.Scene("lowres", 32, 32)
     with pytest.raises(pyrt.RtError):

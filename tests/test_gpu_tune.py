@@ -14,7 +14,8 @@ import pyrt
 from raybatch import ray_batch
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(bool(os.environ.get("RT_BVH_GPU")), reason="RT_BVH_GPU forces the device builder: no host-side tree to tune")]
+              pytest.mark.skipif(bool(os.environ.get("RT_BVH_GPU")) or bool(os.environ.get("RT_NODES")),
+                                 reason="RT_BVH_GPU / RT_NODES force a builder / node format: the tuner works on a host-built tree of 32-byte records")]
 
 
 def bits(a):
