@@ -296,6 +296,11 @@ int rt_bvh_build_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t th
  * is dead code there.) */
 int rt_bvh_check_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t node_format, uint32_t* out8,
                       double* est2);
+/* The host half of the hybrid builder alone (no GPU): the host builder's top down to parts of <= `cutoff` triangles,
+ * CHECKED — the parts and the top's own leaves cover every triangle exactly once, every part is referred to by exactly one
+ * child slot whose box contains its padded geometry, part roots lie within the depth cap with room for their subtrees, the
+ * order is a permutation.  out8 = {top nodes, parts, largest part, deepest part root, depth cap, top leaves, 0, 0}.        */
+int rt_bvh_top_check_host(const rt_scene_desc* scene, uint32_t leaf_max, uint32_t cutoff, uint32_t* out8);
 /* Measured-cost tuning of the host-built BVH (no counterpart in the reference, whose rayTrace is the exhaustive
  * loop of RayTracer.h:27-53; this only changes HOW FAST the same hits are found).  Every tree over the same leaves
  * returns the same hits, so a probe frame traces exactly the same rays whatever the tree and its counters are a

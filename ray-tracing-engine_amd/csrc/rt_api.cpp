@@ -1079,6 +1079,73 @@ int rt_bvh_check_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t node_
   return RT_OK;
 }
 
+int rt_bvh_top_check_host(const rt_scene_desc* sc, uint32_t leaf_max, uint32_t cutoff, uint32_t* out8) {
+  if (!sc || !out8) return fail(RT_ERR_INVALID, "null argument");
+  try {
+    rtbvh::TopBuilt t;
+    rtbvh::buildTop(*sc, leaf_max, cutoff, t);
+    const uint32_t n = sc->n_triangles;
+    if (t.order.size() != n) return fail(RT_ERR_STATE, "top check: the order has %zu entries for %u triangles", t.order.size(), n);
+    std::vector<uint8_t> seenTri(n, 0), covered(n, 0), partRef(t.parts.size(), 0);
+    for (uint32_t id : t.order) {
+      if (id >= n || seenTri[id]++) return fail(RT_ERR_STATE, "top check: the order is not a permutation");
+    }
+    auto geomBox = [&](uint32_t b, uint32_t e, float* lo, float* hi) {
+      for (int a = 0; a < 3; ++a) lo[a] = 3e38f, hi[a] = -3e38f;
+      for (uint32_t i = b; i < e; ++i)
+        for (int k = 0; k < 3; ++k) {
+          const float* q = sc->vertex_pos + 3 * (size_t)sc->tri_vtx[3 * (size_t)t.order[i] + k];
+          for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], q[a]), hi[a] = std::max(hi[a], q[a]);
+        }
+    };
+    uint32_t largest = 0, deepest = 0, topLeaves = 0;
+    for (uint32_t i = 0; i < t.nodes.size(); ++i)
+      for (int c = 0; c < 2; ++c) {
+        const int32_t ref = t.nodes[i].child[c];
+        const float* blo = c ? t.nodes[i].lo1 : t.nodes[i].lo0;
+        const float* bhi = c ? t.nodes[i].hi1 : t.nodes[i].hi0;
+        uint32_t b = 0, e = 0;
+        if (ref >= 0) {
+          if ((uint32_t)ref >= t.nodes.size() || (uint32_t)ref == i) return fail(RT_ERR_STATE, "top check: bad inner ref");
+          continue;
+        }
+        const uint32_t code = ~(uint32_t)ref;
+        if (code & rtbvh::kPartFlag) {
+          const uint32_t k = code & (rtbvh::kPartFlag - 1u);
+          if (k >= t.parts.size() || partRef[k]++) return fail(RT_ERR_STATE, "top check: part %u referred to twice or out of range", k);
+          const rtbvh::TopBuilt::Part& P = t.parts[k];
+          if (P.parent != i || P.slot != (uint32_t)c) return fail(RT_ERR_STATE, "top check: part %u names another referrer", k);
+          b = P.b, e = P.e;
+          if (e <= b || e > n || e - b > cutoff || e - b <= t.leafMax) return fail(RT_ERR_STATE, "top check: part %u has %u triangles", k, e - b);
+          largest = std::max(largest, e - b), deepest = std::max(deepest, P.depth);
+          // its subtree must still fit below: ceil(log2(triangles / leafMax)) more levels at least
+          uint32_t need = 0;
+          for (uint32_t m = e - b; m > t.leafMax; m = (m + 1) / 2) ++need;
+          if ((int)(P.depth + need) > t.depthCap) return fail(RT_ERR_STATE, "top check: part %u at depth %u cannot be split within the cap %d", k, P.depth, t.depthCap);
+        } else {
+          b = code >> 3, e = b + (code & 7u) + 1u;
+          if (e > n || e - b > t.leafMax) return fail(RT_ERR_STATE, "top check: bad leaf");
+          ++topLeaves;
+        }
+        for (uint32_t j = b; j < e; ++j)
+          if (covered[j]++) return fail(RT_ERR_STATE, "top check: position %u of the order is covered twice", j);
+        float lo[3], hi[3];
+        geomBox(b, e, lo, hi);
+        for (int a = 0; a < 3; ++a)
+          if (!(blo[a] <= lo[a] - 0.999f * t.pad && bhi[a] >= hi[a] + 0.999f * t.pad)) return fail(RT_ERR_STATE, "top check: a child box does not contain its padded geometry");
+      }
+    for (uint32_t j = 0; j < n; ++j)
+      if (covered[j] != 1) return fail(RT_ERR_STATE, "top check: position %u of the order is not covered", j);
+    for (size_t k = 0; k + 1 < t.parts.size(); ++k)
+      if (t.parts[k].b >= t.parts[k + 1].b) return fail(RT_ERR_STATE, "top check: parts are not in order");
+    out8[0] = (uint32_t)t.nodes.size(), out8[1] = (uint32_t)t.parts.size(), out8[2] = largest, out8[3] = deepest;
+    out8[4] = (uint32_t)t.depthCap, out8[5] = topLeaves, out8[6] = out8[7] = 0;
+  } catch (const std::exception& e) {
+    return fail(RT_ERR_INVALID, "top check failed: %s", e.what());
+  }
+  return RT_OK;
+}
+
 int rt_bvh_tune(rt_ctx* c, const rt_params* probe, double budget_seconds, uint32_t max_probes, rt_tune_report* out) {
   if (!c || !probe) return fail(RT_ERR_INVALID, "ctx/probe is null");
   if (out) memset(out, 0, sizeof *out);

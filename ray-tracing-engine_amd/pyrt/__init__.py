@@ -93,7 +93,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("mesh", "<u4"), ("tri", "<u4"), ("vtx", "
 # every symbol include/rt_amd.h / include/rt_host.h declares
 AMD_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_set_photons", "rt_emit_photons",
                "rt_render", "rt_render_passes", "rt_render_device", "rt_resolve_device", "rt_trace", "rt_knn", "rt_bvh_info_get",
-               "rt_bvh_export", "rt_bvh_build_host", "rt_bvh_check_host", "rt_bvh_tune", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
+               "rt_bvh_export", "rt_bvh_build_host", "rt_bvh_check_host", "rt_bvh_top_check_host", "rt_bvh_tune", "rt_profile_reset", "rt_profile_collect", "rt_test_unit",
                "rt_trace_stream_device", "rt_build_photon_map", "rt_get_photons", "rt_test_kd_order", "rt_owned_granules", "rt_pack_owned_device", "rt_unpack_owned_device", "rt_group_create", "rt_group_destroy",
                "rt_group_size", "rt_group_uses_rccl", "rt_group_ctx", "rt_group_set_photons", "rt_group_render"]
 HOST_SYMBOLS = ["rt_host_scene_build", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error",
@@ -145,6 +145,7 @@ def amd():
         L.rt_bvh_build_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.POINTER(BvhInfo),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.rt_bvh_check_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rt_bvh_top_check_host.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p]
         L.rt_profile_reset.argtypes = [C.c_void_p]
         L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.rt_test_unit.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -264,6 +265,14 @@ def bvh_check_host(scene, leaf_max=0, node_format=NODES_F16):
     _check(amd().rt_bvh_check_host(C.byref(scene.desc), leaf_max, node_format, _ptr(out), _ptr(est)))
     return dict(nodes=int(out[0]), slots=int(out[1]), blocks=int(out[2]), depth=int(out[3]), added_nodes=int(out[4]),
                 visits_float=float(est[0]), visits_packed=float(est[1]))
+
+
+def bvh_top_check_host(scene, leaf_max=0, cutoff=1024):
+    """The hybrid builder's host half (rtbvh::buildTop) alone, validated (no GPU).  Returns a dict of the shape numbers."""
+    out = np.zeros(8, np.uint32)
+    _check(amd().rt_bvh_top_check_host(C.byref(scene.desc), leaf_max, cutoff, _ptr(out)))
+    return dict(top_nodes=int(out[0]), parts=int(out[1]), largest_part=int(out[2]), deepest_part=int(out[3]), depth_cap=int(out[4]),
+                top_leaves=int(out[5]))
 
 
 def kd_order(pos, dir_, weight=None):

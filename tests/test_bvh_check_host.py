@@ -65,3 +65,19 @@ def test_tuner_machinery_on_a_host_computable_cost(kind, monkeypatch):
     assert tuned["visits_float"] <= base["visits_float"]
     if kind == "lowres":
         assert tuned["visits_float"] < 0.995 * base["visits_float"]
+
+
+@pytest.mark.parametrize("kind,cutoff", [("lowres", 64), ("lowres", 1024), ("hires", 256), ("hires", 1024), ("stress", 1024)])
+def test_hybrid_builders_host_top_is_a_valid_partial_tree(kind, cutoff):
+    """rtbvh::buildTop (what rt_create runs on the host for RT_BVH_HYBRID): the host builder's own splits down to parts of at
+    most `cutoff` triangles.  Parts and top leaves cover the order exactly once, every part has one referrer whose box contains
+    its padded geometry, and there is depth left for every part's subtree."""
+    s = pyrt.Scene(kind, 32, 32)
+    r = pyrt.bvh_top_check_host(s, 0, cutoff)
+    n = s.desc.n_triangles
+    assert r["parts"] >= 2 and 2 < r["largest_part"] <= cutoff and r["top_nodes"] >= r["parts"] // 2
+    assert r["deepest_part"] < r["depth_cap"]
+    if kind == "stress":
+        assert 1000 < r["parts"] < 4000 and r["top_nodes"] < 4000  # (1,450 parts for 1 M triangles: the device does the rest)
+    with pytest.raises(pyrt.RtError):
+        pyrt.bvh_top_check_host(s, 0, max(n, 3))  # a single part: nothing to build on the host
