@@ -313,10 +313,15 @@ int launch_frame(rt_ctx* c, const rt_params* p, float4* dAccum, hipStream_t stre
   // a root-to-leaf path of depth d passes d inner nodes and each stacks at most one
   // far child, so d entries suffice
   uint32_t levels = c->bvh.maxDepth > 1 ? c->bvh.maxDepth : 1;
+  A.kd16 = 0;
   if (p->use_photons) {
     uint32_t kd = 1;
     while ((1ull << kd) <= c->S.n_photons) ++kd;
-    levels = levels > kd + 1 ? levels : kd + 1;
+    // the walk's stack: a sentinel + at most one pending far child per tree level + the row written ahead of the top;
+    // 16-bit entries (two per word) when every photon index fits
+    A.kd16 = c->S.n_photons < 65535u ? 1u : 0u;
+    const uint32_t kdRows = A.kd16 ? (kd + 2u + 1u) / 2u : kd + 1u;
+    levels = levels > kdRows ? levels : kdRows;
   }
   // (+1: row 0 of a lane's stack is the TERM sentinel, rt_kernels.hip Trav)
   A.stackLevels = (levels > (uint32_t)rtbvh::kMaxDepth ? (uint32_t)rtbvh::kMaxDepth : levels) + 1u;

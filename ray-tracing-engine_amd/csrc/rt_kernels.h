@@ -64,7 +64,9 @@ struct RenderArgs {
   uint32_t n_tiles;
   uint32_t width, height, spp, s0, s1, mode, max_depth, seed, k, photons_requested;
   uint32_t flags;         // bit 0: shadow rays through the wave-level pool
-  uint32_t stackLevels;   // LDS traversal-stack entries per lane (BVH depth; kd depth + 1 with photons)
+  uint32_t stackLevels;   // LDS traversal-stack rows (64 words each) per wave: BVH depth + 1; with photons also the kd walk's
+                          // pending entries (kd depth + 2: 32-bit, or two 16-bit entries per word when kd16)
+  uint32_t kd16;          // the k-NN walk keeps 16-bit stack entries (fewer than 65,535 photons)
   uint32_t sshift;        // a wave = (64 >> sshift) pixels x (1 << sshift) samples side by side
   uint32_t tileW, tileH;  // pixel footprint of one wave (tileW * tileH == 64 >> sshift)
   uint32_t tilesPerBlock; // one-wave-per-workgroup kernels (k_render): consecutive wave tiles a workgroup renders (launcher)

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "bvh_build.h"
 #include "rt_device.h"
@@ -621,8 +622,13 @@ RT_DEV float photon_dist(const DevScene& S, uint32_t n, f3 p, float4& pos) {
 // (With k = 1 "the remaining k - 1" is empty and front() is the PREVIOUS insert, which may be larger than the one
 // before: there only the reference's own test runs.)  The reference's own test is much weaker whenever m_bestdist < 1.
 // After the call the heap holds the k results in ascending distance order.
+// S16: the pending far children as 16-bit indices (maps of fewer than 65,535 photons: config 3's 35,744): half the stack's LDS,
+// which with the k-heap is what caps the photon kernel's waves per CU.
 constexpr uint32_t KD_NONE = 0x3fffffffu;
+template <bool S16>
 RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, uint32_t* stack) {
+  using Entry = typename std::conditional<S16, uint16_t, uint32_t>::type;
+  constexpr uint32_t NONE_E = S16 ? 0xffffu : KD_NONE;
   float4 pos;
   for (int j = 0; j < k; j++) H.set(j, photon_dist(S, (uint32_t)j, p, pos), (uint32_t)j);
   H.make(k);
@@ -630,8 +636,9 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, uint32_
   float skip2 = (float)(bestdist * bestdist * (1.0 + 1e-6));
   uint32_t visited = 0;
   const bool mono = k >= 2;  // m_bestdist is non-increasing
-  uint32_t* top = stack;
-  *top = KD_NONE;  // row 0: the sentinel an empty stack pops
+  // (this lane's column: [row][lane] entries; 16-bit entries pack two rows into one of the stack's 256-byte rows)
+  Entry* top = S16 ? reinterpret_cast<Entry*>(stack - (threadIdx.x & 63u)) + (threadIdx.x & 63u) : reinterpret_cast<Entry*>(stack);
+  *top = (Entry)NONE_E;  // row 0: the sentinel an empty stack pops
   uint32_t cur = S.n_photons / 2u;  // the root: the median of [0, n)
   bool popped = false;
   while (cur != KD_NONE) {
@@ -677,14 +684,15 @@ RT_DEV uint32_t knn_query(const DevScene& S, f3 p, int k, const Heap& H, uint32_
         const double dxd = (double)dx;
         const bool out1 = dxd * dxd >= bestdist, out2 = (dxd < 0 ? -dxd : dxd) * (1.0 - 4.8e-7) >= bestdist;
         const bool record = (far != KD_NONE) & (!mono | !(out1 | out2));
-        top[BLOCK] = far;
+        top[BLOCK] = (Entry)far;  // (KD_NONE truncates to the 16-bit sentinel)
         top += record ? BLOCK : 0;
       }
     }
     popped = next == KD_NONE;
     if (popped) {
-      next = *top;
-      if (next != KD_NONE) top -= BLOCK;  // (the sentinel stays)
+      const uint32_t e = *top;
+      next = e == NONE_E ? KD_NONE : e;
+      if (e != NONE_E) top -= BLOCK;  // (the sentinel stays)
     }
     cur = next;
   }
@@ -733,7 +741,7 @@ RT_DEV f3 shade_photon(const DevScene& S, const RenderArgs& A, f3 rayDir, const 
   const Heap H{L.heap};
   const int k = (int)A.k;
   st.knn++;
-  const uint32_t vis = knn_query(S, point, k, H, L.stack);
+  const uint32_t vis = A.kd16 ? knn_query<true>(S, point, k, H, L.stack) : knn_query<false>(S, point, k, H, L.stack);
   if (STATS) st.kd += vis;
   const float4 far = S.phPos[H.I(k - 1)];
   const float r = dist3(mk(far.x, far.y, far.z), point);
@@ -1436,7 +1444,7 @@ __global__ __launch_bounds__(BLOCK) void k_knn(DevScene S, const float* __restri
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const Heap H{L.heap};
-  const uint32_t vis = knn_query(S, ld(q + 3 * (size_t)i), (int)k, H, L.stack);
+  const uint32_t vis = knn_query<false>(S, ld(q + 3 * (size_t)i), (int)k, H, L.stack);
   for (uint32_t j = 0; j < k; j++) {
     idx[(size_t)i * k + j] = H.I((int)j);
     dst[(size_t)i * k + j] = H.D((int)j);
@@ -1727,7 +1735,9 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
   A1.tilesPerBlock = 1u;  // (more wave tiles per workgroup unbalance the grid: C3 13.7 / 14.8 / 17.8 ms at 4 / 8 / 16 in round 3)
   const uint32_t nBlocks = blocks;
   // Occupancy target (waves per SIMD) of the one-wave-per-workgroup kernels.
-  constexpr int MINW = PHOTON ? 2 : 4;
+  // (the photon kernel at 5 waves per SIMD: its walk waits on L1-hit loads half of its life; 96 VGPRs cost 12 spilled registers
+  // outside the walk, and the 16-bit stack makes the LDS room — measured: C3 7.3 -> see DESIGN.md 4.6)
+  constexpr int MINW = PHOTON ? 5 : 4;
   if (stats) hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, true, 1>), dim3(nBlocks), dim3(BLOCK), ldsBytes, stream, S, A1, accum, counters);
   else {
     hipLaunchKernelGGL((k_render<BRUTE, PHOTON, POOLED, false, MINW>), dim3(nBlocks), dim3(BLOCK), ldsBytes, stream, S, A1, accum, counters);
