@@ -81,3 +81,17 @@ def test_hybrid_builders_host_top_is_a_valid_partial_tree(kind, cutoff):
         assert 1000 < r["parts"] < 4000 and r["top_nodes"] < 4000  # (1,450 parts for 1 M triangles: the device does the rest)
     with pytest.raises(pyrt.RtError):
         pyrt.bvh_top_check_host(s, 0, max(n, 3))  # a single part: nothing to build on the host
+
+
+@pytest.mark.parametrize("kind", ["identical", "line", "corner", "flat", "random"])
+def test_host_builders_survive_hard_soups(kind):
+    """tests/soups.py: coincident triangles, collinear centroids with wildly different sizes, a dense cluster beside scene-sized
+    triangles, a flat sheet, a random soup — at a size where RT_BVH_AUTO takes the hybrid builder.  The host top, the float tree
+    and both packed formats must be valid trees within the depth cap (the GPU side: tests/test_gpu_soups.py)."""
+    import soups
+    s = soups.soup(kind, 140000)
+    top = pyrt.bvh_top_check_host(s, 0, 1024)
+    assert top["parts"] >= 137 and top["largest_part"] <= 1024 and top["deepest_part"] < top["depth_cap"]
+    for fmt in (pyrt.NODES_F16, pyrt.NODES_Q8):
+        r = pyrt.bvh_check_host(s, 0, fmt)
+        assert 70000 <= r["nodes"] < 140000 and r["depth"] < 32

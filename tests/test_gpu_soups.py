@@ -1,0 +1,51 @@
+"""Builders under geometry they were not tuned on.  rt_create picks the hybrid builder by itself from 131,072 triangles
+(RT_BVH_AUTO), so it has to survive what a caller may hand it: coincident triangles (no split separates anything), collinear
+centroids with sizes six orders of magnitude apart, a dense cluster beside scene-sized triangles, a flat sheet, a random soup
+(tests/soups.py).  Every builder and both node formats must return the exhaustive loop's hits — which are the oracle's."""
+import numpy as np
+import pytest
+
+import orc
+import pyrt
+import soups
+
+pytestmark = pytest.mark.gpu
+
+N = 140000
+
+
+@pytest.mark.parametrize("kind", soups.KINDS)
+def test_every_builder_is_exact_on_hard_soups(kind):
+    s = soups.soup(kind, N)
+    rays = soups.soup_rays(s, 3000)
+    want = None
+    for builder, fmt in ((pyrt.BVH_AUTO, pyrt.NODES_AUTO), (pyrt.BVH_HOST, pyrt.NODES_F16), (pyrt.BVH_DEVICE, pyrt.NODES_F16),
+                         (pyrt.BVH_HYBRID, pyrt.NODES_Q8), (pyrt.BVH_DEVICE, pyrt.NODES_Q8)):
+        ctx = pyrt.Context(s, bvh_builder=builder, node_format=fmt)
+        bi = ctx.bvh_info()
+        assert bi.n_tri_records == N and bi.max_depth < 32
+        if want is None:
+            want = ctx.trace(rays, pyrt.ACCEL_BRUTE)
+            assert want["hit"].sum() > len(rays) // 4  # (the rays are aimed at triangles)
+            # ... and the exhaustive loop is the oracle's (a sample: 140 k tests per ray on one host core)
+            ref = orc.trace(s, rays[:200])
+            assert np.array_equal(want[:200].view(np.uint8), ref.view(np.uint8))
+        got = ctx.trace(rays, pyrt.ACCEL_BVH)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (kind, builder, fmt)
+        assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BVH, pyrt.TRACE_ANY)["hit"], want["hit"]), (kind, builder, fmt)
+        ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["corner", "random"])
+def test_frames_on_hard_soups_agree_across_builders(kind):
+    """One small frame per builder (pooled kernel, the stacks sized by each tree's own depth): the same accumulators."""
+    s = soups.soup(kind, N)
+    p = pyrt.make_params(32, 32, 2, seed=3)
+    frames = []
+    for builder in (pyrt.BVH_AUTO, pyrt.BVH_HOST, pyrt.BVH_DEVICE):
+        ctx = pyrt.Context(s, bvh_builder=builder)
+        _, acc, st = ctx.render(p)
+        frames.append((acc.copy(), st.rays_closest, st.rays_shadow))
+        ctx.close()
+    for f in frames[1:]:
+        assert np.array_equal(f[0].view(np.uint32), frames[0][0].view(np.uint32)) and f[1:] == frames[0][1:]
