@@ -789,7 +789,7 @@ float halfToFloat(uint16_t hv) {
   return sign ? -v : v;
 }
 
-ScenePlan planScene(const rt_scene_desc& sc, uint32_t leafMax) {
+ScenePlan planSceneExact(const rt_scene_desc& sc, uint32_t leafMax, std::vector<float>& sizeKey, uint32_t threads) {
   ScenePlan P;
   if (leafMax == 0) leafMax = 2;
   if (leafMax > 8) leafMax = 8;
@@ -797,25 +797,57 @@ ScenePlan planScene(const rt_scene_desc& sc, uint32_t leafMax) {
   if (sc.n_triangles == 0 || sc.n_triangles >= (1u << 28)) throw std::runtime_error("triangle count out of range");
   if (sc.mesh_tri_begin[sc.n_meshes] != sc.n_triangles || sc.mesh_vtx_begin[sc.n_meshes] != sc.n_vertices)
     throw std::runtime_error("mesh offset tables inconsistent with counts");
-  for (uint32_t m = 0; m < sc.n_meshes; ++m) {
+  for (uint32_t m = 0; m < sc.n_meshes; ++m)
     if (sc.mesh_tri_begin[m] > sc.mesh_tri_begin[m + 1]) throw std::runtime_error("mesh_tri_begin not monotone");
-    for (uint32_t t = sc.mesh_tri_begin[m]; t < sc.mesh_tri_begin[m + 1]; ++t)
+  uint32_t T = threads ? threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("RT_BVH_THREADS")) T = std::max(1, atoi(e));
+  T = std::max(1u, std::min({T, 64u, sc.n_triangles / 32768u + 1u}));
+  sizeKey.resize(sc.n_triangles);
+  std::vector<float> mx(T, 0.f);
+  std::vector<int> bad(T, 0);
+  auto work = [&](uint32_t th) {
+    const uint32_t tb = (uint32_t)((uint64_t)sc.n_triangles * th / T), te = (uint32_t)((uint64_t)sc.n_triangles * (th + 1) / T);
+    uint32_t m = 0;
+    while (m + 1 < sc.n_meshes && sc.mesh_tri_begin[m + 1] <= tb) ++m;
+    float localMax = 0.f;
+    for (uint32_t t = tb; t < te; ++t) {
+      while (t >= sc.mesh_tri_begin[m + 1]) ++m;  // (empty meshes are skipped; the tables were checked above)
+      float lo[3], hi[3];
       for (int k = 0; k < 3; ++k) {
         const uint32_t v = sc.tri_vtx[3 * static_cast<size_t>(t) + k];
-        if (v < sc.mesh_vtx_begin[m] || v >= sc.mesh_vtx_begin[m + 1])
-          throw std::runtime_error("triangle references a vertex outside its mesh");
+        if (v < sc.mesh_vtx_begin[m] || v >= sc.mesh_vtx_begin[m + 1]) {
+          bad[th] = 1;
+          return;
+        }
         const float* q = sc.vertex_pos + 3 * static_cast<size_t>(v);
         for (int a = 0; a < 3; ++a) {
-          if (!std::isfinite(q[a])) throw std::runtime_error("non-finite vertex position");
-          P.maxAbs = std::max(P.maxAbs, std::fabs(q[a]));
+          if (!std::isfinite(q[a])) {
+            bad[th] = 2;
+            return;
+          }
+          localMax = std::max(localMax, std::fabs(q[a]));
+          lo[a] = k ? std::min(lo[a], q[a]) : q[a], hi[a] = k ? std::max(hi[a], q[a]) : q[a];
         }
       }
+      sizeKey[t] = -std::log2(std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-30f}));  // (Builder::loadPrims' c[3])
+    }
+    mx[th] = localMax;
+  };
+  {
+    std::vector<std::thread> pool;
+    for (uint32_t th = 1; th < T; ++th) pool.emplace_back(work, th);
+    work(0);
+    for (std::thread& x : pool) x.join();
+  }
+  for (uint32_t th = 0; th < T; ++th) {
+    if (bad[th] == 1) throw std::runtime_error("triangle references a vertex outside its mesh");
+    if (bad[th] == 2) throw std::runtime_error("non-finite vertex position");
+    P.maxAbs = std::max(P.maxAbs, mx[th]);
   }
   int levels = 0;
   for (uint32_t n = sc.n_triangles; n > leafMax; n = (n + 1) / 2) ++levels;
   const char* slack = getenv("RT_BVH_SLACK");
-  // (the plan is what the DEVICE builder works from; the host builder sets its own cap in build())
-  P.depthCap = std::min(kMaxDepth - 1, levels + (slack ? atoi(slack) : defaultDepthSlack(levels, false)));
+  P.depthCap = std::min(kMaxDepth - 1, levels + (slack ? atoi(slack) : defaultDepthSlack(levels)));  // (as build() / buildTop())
   float padRef = std::max(1.f, P.maxAbs);
   for (int a = 0; a < 3; ++a)
     if (std::isfinite(sc.camera.position[a])) padRef = std::max(padRef, std::fabs(sc.camera.position[a]));
@@ -829,7 +861,6 @@ ScenePlan planScene(const rt_scene_desc& sc, uint32_t leafMax) {
   P.boxScale = std::ldexp(1.f, std::min(std::max(e - 1, -100), 100));
   return P;
 }
-
 
 // Final node numbering: the kTop nodes a ray is most likely to visit first — taken
 // greedily by box surface area from the root, so the set is closed under "parent of" and

@@ -101,13 +101,10 @@ constexpr uint32_t wavesForDepth(int depth) {
 // 14 waves = 402 / 415 / 416 / 393 ms with 37.5 / 36.7 / 36.7 / 35.0 node visits per ray; 8 M triangles
 // (22 levels) +2 ... +5 all 14 waves = 73.3 / 71.7 / 71.8 / 63.9 ms, +6 (13 waves) 68.6 ms.  So: up to 5
 // spare levels as long as 14 waves (or as many as +2 levels leave) still fit.
-// `sweepBuilder` = the host builder.  The device builder's Morton-cell splits gain nothing from a deeper cap
-// (1 M triangles: 433 ms at 21 levels / 16 waves, 466 ms at 24 / 14), so it only takes the spare levels
-// that cost no wave at all.
-constexpr int defaultDepthSlack(int levels, bool sweepBuilder = true) {
+constexpr int defaultDepthSlack(int levels) {
   if (levels < 19) return 3;
   const uint32_t keep = wavesForDepth(levels + 2);
-  const uint32_t floorWaves = !sweepBuilder ? keep : keep < 14u ? keep : 14u;
+  const uint32_t floorWaves = keep < 14u ? keep : 14u;
   int s = 2;
   while (s < 5 && levels + s + 1 < kMaxDepth && wavesForDepth(levels + s + 1) >= floorWaves) ++s;
   return s;
@@ -131,15 +128,17 @@ struct Built {
   uint32_t q8Shift = 0, q8Blocks = 0;
 };
 
-// What both builders (host: build(); device: csrc/bvh_gpu.hip) derive from the scene
-// before touching a triangle: validation (throws std::runtime_error on an inconsistent
-// description), the leaf size, the depth cap, the box padding and the f16 plane scale.
+// What the device builder (csrc/bvh_gpu.hip) takes from the host before it touches a triangle: validation (throws
+// std::runtime_error on an inconsistent description), the leaf size, the HOST builder's depth cap, the box padding, the f16
+// plane scale — and per triangle the SIZE key the host builder's splits bin and sweep along beside the three centroid axes
+// (-log2 of the longest box edge: the host's libm, so that both builders see the same bits).  One pass shared by `threads`
+// threads (0 = as build()).
 struct ScenePlan {
   uint32_t leafMax = 2;
   int depthCap = kMaxDepth - 1;  // deepest leaf level the tree may use (root = 0)
   float maxAbs = 0.f, pad = 0.f, originBound = 0.f, boxScale = 1.f;
 };
-ScenePlan planScene(const rt_scene_desc& scene, uint32_t leafMax);
+ScenePlan planSceneExact(const rt_scene_desc& scene, uint32_t leafMax, std::vector<float>& sizeKey, uint32_t threads = 0);
 uint16_t toHalfDirected(float x, bool up);
 float halfToFloat(uint16_t h);
 

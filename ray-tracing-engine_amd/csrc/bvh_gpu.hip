@@ -6,31 +6,24 @@
 // triangle records in leaf order, leaves of <= leafMax triangles, depth <= the plan's cap —
 // so every exactness test runs unchanged on a device-built tree (RT_BVH_GPU=1).
 //
-//   1. per-triangle boxes + centroids, centroid bounds (one pass, ordered-int atomics);
-//   2. sort key = 2-bit SIZE CLASS (triangles whose box spans > 1/4, 1/16, 1/64 of the scene
-//      extent come first: a wall quad must not sit in the middle of a mesh's Morton range,
-//      where every range box containing it would be the whole room) + 60-bit Morton code of
-//      the centroid; radix sort (rocPRIM) of (key, triangle); equal keys keep ascending
-//      triangle order (stable sort): deterministic;
-//   3. a min/max segment tree over the sorted triangle boxes: the box of ANY contiguous
-//      range of the Morton order in ~2 log n steps;
-//   4. top-down, one launch set per tree level, one WAVE per node: the 64 lanes evaluate
-//      the SAH cost (area x ceil(n / leafMax), the host builder's) of up to 64 split
-//      positions of the node's Morton range — every position for ranges of <= 65
-//      triangles, and always the positions where the size class changes — restricted to
-//      splits whose sides still fit the remaining depth budget, and a wave-min picks the
-//      cheapest (lowest position on ties);
-//   5. children are numbered by an exclusive scan over the level (breadth-first node
-//      order: the top of the tree is a prefix of the array, as the LDS-resident top wants),
-//      nodes are written packed with the plan's padding and plane scale.
-//   6. (round 3) ranges of <= kSubMax triangles leave the Morton order: ONE WORKGROUP per range builds
-//      the whole subtree with the host builder's exact sweep — per level and axis a bitonic sort of
-//      the range's segments by centroid (LDS), segmented prefix / suffix box scans, the SAH cost of
-//      every split position, an atomic min per segment — and reorders the range's triangles; the
-//      subtrees are then numbered behind the top (scan of their node counts) and packed.
-//      Measured: a Morton-cut top over exact subtrees of <= 1,024 triangles is within
-//      -2 ... +4 % of the host tree's node visits per ray; Morton cuts all the way down cost +19 ... 29 %.
-// Quality: measured nodes/ray vs the host SAH tree are in DESIGN.md.  Cost: a few ms for 1 M triangles.
+//   1. per-triangle boxes; the size keys come from the host (rtbvh::planSceneExact);
+//   2. THE TOP (ranges of more than kSubMax = 1,024 triangles): the host builder's split rules as kernels, one level of the
+//      tree per round of launches (k_top_*): binned SAH over the three centroid axes and the size axis above 4,096 triangles
+//      — bounds, bins of all four axes in one pass, the choice, a stable partition —, the exact sweep over the same four
+//      axes below (one workgroup per range: bitonic sorts by (key, id), suffix / prefix box scans, every cut priced), the
+//      depth budget, the host's tie rules.  Everything the host derives from min / max / counts or from sorts under a total
+//      order comes out the same here, so the splits — and the tree — are the host builder's;
+//   3. THE SUBTREES (round 3): one workgroup per range of <= kSubMax triangles builds the whole subtree with the exact
+//      sweep — per level and axis a bitonic sort of the range's segments by centroid (LDS), segmented prefix / suffix box
+//      scans, the SAH cost of every split position, an atomic min per segment — and reorders the range's triangles; the
+//      subtrees are numbered behind the top (scan of their node counts);
+//   4. the host builder's rotation passes as kernels (one launch per depth, bottom-up), a pre-order renumbering, the
+//      packing with the smaller child box in slot 0; the triangle records in leaf order.
+// The HYBRID build takes step 2 from the host (rtbvh::buildTop) — the fall-back when a range needs the host's median split.
+// (Rounds 2-3 had a Morton-order top here — radix sort, segment tree of boxes, 64 candidate cuts per range —: +4 ... +7 % node
+// visits against the host tree; removed in round 4, code at commit 286f27d.)
+// Result and cost (profiles/r04_builders.txt): the host builder's node visits per ray to the last digit on all
+// four scenes, 1 M triangles in 21 ms (host: 170-180 ms).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -39,7 +32,6 @@
 #include <cstring>  // (rocPRIM's headers use memset without including it)
 #include <vector>
 
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "bvh_build.h"
@@ -48,9 +40,6 @@
 namespace rtk {
 namespace {
 
-struct WorkItem {
-  uint32_t b, e;  // Morton-order range
-};
 // a range small enough for the exact builder (k_subtree): its place in the tree is patched in afterwards
 struct SubItem {
   uint32_t b, e;
@@ -66,107 +55,23 @@ __device__ __forceinline__ int fkey(float f) {  // order-preserving float -> int
 }
 __device__ __forceinline__ float funkey(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-__global__ void k_init_bounds(int* cb) {
-  if (threadIdx.x < 3) cb[threadIdx.x] = 0x7fffffff;        // min
-  else if (threadIdx.x < 6) cb[threadIdx.x] = (int)0x80000000;  // max
-}
-
-// triangle boxes (float4 lo, hi) in REFERENCE order, centroid bounds
+// triangle boxes (float4 lo, hi) in REFERENCE order
 __global__ void k_tri_boxes(const float* __restrict__ vpos, const uint4* __restrict__ triShade, uint32_t n,
-                            float4* __restrict__ lo, float4* __restrict__ hi, int* __restrict__ cb) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  float c[3] = {0.f, 0.f, 0.f};
-  const bool on = t < n;
-  if (on) {
-    const uint4 tv = triShade[t];
-    float l[3], h[3];
-    for (int a = 0; a < 3; ++a) {
-      const float p0 = vpos[3 * (size_t)tv.x + a], p1 = vpos[3 * (size_t)tv.y + a], p2 = vpos[3 * (size_t)tv.z + a];
-      l[a] = fminf(p0, fminf(p1, p2)), h[a] = fmaxf(p0, fmaxf(p1, p2));
-      c[a] = 0.5f * l[a] + 0.5f * h[a];
-    }
-    lo[t] = make_float4(l[0], l[1], l[2], 0.f), hi[t] = make_float4(h[0], h[1], h[2], 0.f);
-  }
-  for (int a = 0; a < 3; ++a) {
-    int mn = on ? fkey(c[a]) : 0x7fffffff, mx = on ? fkey(c[a]) : (int)0x80000000;
-    for (int off = 32; off > 0; off >>= 1) {
-      mn = min(mn, __shfl_xor(mn, off, 64));
-      mx = max(mx, __shfl_xor(mx, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) atomicMin(&cb[a], mn), atomicMax(&cb[3 + a], mx);
-  }
-}
-
-__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // 21 bits -> every third bit
-  uint64_t x = v & 0x1fffffu;
-  x = (x | x << 32) & 0x1f00000000ffffull;
-  x = (x | x << 16) & 0x1f0000ff0000ffull;
-  x = (x | x << 8) & 0x100f00f00f00f00full;
-  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-  x = (x | x << 2) & 0x1249249249249249ull;
-  return x;
-}
-
-__global__ void k_morton(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n, const int* __restrict__ cb,
-                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                            float4* __restrict__ lo, float4* __restrict__ hi) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const float4 l = lo[t], h = hi[t];
-  const float c[3] = {0.5f * l.x + 0.5f * h.x, 0.5f * l.y + 0.5f * h.y, 0.5f * l.z + 0.5f * h.z};
-  const float d[3] = {h.x - l.x, h.y - l.y, h.z - l.z};
-  uint64_t code = 0;
-  float sceneExt = 0.f, triExt = 0.f;
+  const uint4 tv = triShade[t];
+  float l[3], h[3];
   for (int a = 0; a < 3; ++a) {
-    const float mn = funkey(cb[a]), mx = funkey(cb[3 + a]);
-    const float ext = mx - mn;
-    sceneExt = fmaxf(sceneExt, ext), triExt = fmaxf(triExt, d[a]);
-    float u = ext > 0.f ? (c[a] - mn) / ext : 0.f;
-    u = fminf(fmaxf(u, 0.f), 1.f);
-    const uint32_t q = (uint32_t)fminf(u * 1048576.f, 1048575.f);  // 20 bits per axis
-    code |= spread21(q) << (2 - a);
+    const float p0 = vpos[3 * (size_t)tv.x + a], p1 = vpos[3 * (size_t)tv.y + a], p2 = vpos[3 * (size_t)tv.z + a];
+    l[a] = fminf(p0, fminf(p1, p2)), h[a] = fmaxf(p0, fmaxf(p1, p2));
   }
-  // size class: 0 = spans more than a quarter of the scene ... 3 = the small rest
-  const float rel = sceneExt > 0.f ? triExt / sceneExt : 0.f;
-  const uint64_t cls = rel > 0.25f ? 0u : rel > 0.0625f ? 1u : rel > 0.015625f ? 2u : 3u;
-  keys[t] = (cls << 60) | code, vals[t] = t;
-}
-
-// segment tree over the sorted triangle boxes: seg[N2 + i] = box of sorted triangle i
-__global__ void k_seg_leaves(const float4* __restrict__ lo, const float4* __restrict__ hi, const uint32_t* __restrict__ order,
-                             uint32_t n, uint32_t N2, float4* __restrict__ segLo, float4* __restrict__ segHi) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N2) return;
-  const float inf = __int_as_float(0x7f800000);
-  segLo[N2 + i] = i < n ? lo[order[i]] : make_float4(inf, inf, inf, 0.f);
-  segHi[N2 + i] = i < n ? hi[order[i]] : make_float4(-inf, -inf, -inf, 0.f);
-}
-__global__ void k_seg_level(uint32_t first, uint32_t count, float4* __restrict__ segLo, float4* __restrict__ segHi) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const uint32_t j = first + i;
-  const float4 a = segLo[2 * j], b = segLo[2 * j + 1], c = segHi[2 * j], d = segHi[2 * j + 1];
-  segLo[j] = make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), 0.f);
-  segHi[j] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0.f);
+  lo[t] = make_float4(l[0], l[1], l[2], 0.f), hi[t] = make_float4(h[0], h[1], h[2], 0.f);
 }
 
 struct Box3 {
   float lx, ly, lz, hx, hy, hz;
 };
-__device__ __forceinline__ Box3 range_box(const float4* __restrict__ segLo, const float4* __restrict__ segHi, uint32_t N2,
-                                          uint32_t b, uint32_t e) {
-  const float inf = __int_as_float(0x7f800000);
-  Box3 r{inf, inf, inf, -inf, -inf, -inf};
-  auto eat = [&](uint32_t j) {
-    const float4 l = segLo[j], h = segHi[j];
-    r.lx = fminf(r.lx, l.x), r.ly = fminf(r.ly, l.y), r.lz = fminf(r.lz, l.z);
-    r.hx = fmaxf(r.hx, h.x), r.hy = fmaxf(r.hy, h.y), r.hz = fmaxf(r.hz, h.z);
-  };
-  for (uint32_t l = b + N2, rr = e + N2; l < rr; l >>= 1, rr >>= 1) {
-    if (l & 1u) eat(l++);
-    if (rr & 1u) eat(--rr);
-  }
-  return r;
-}
 __device__ __forceinline__ float half_area(const Box3& b) {
   const float dx = b.hx - b.lx, dy = b.hy - b.ly, dz = b.hz - b.lz;
   return dx < 0.f ? 0.f : dx * dy + dy * dz + dz * dx;
@@ -202,141 +107,6 @@ __device__ __forceinline__ uint32_t half_directed(float x, bool up) {
     h = au - ((127u - 15u) << 10);
   }
   return (sign << 15) | h;
-}
-
-// One wave per node of this level: choose the split, count the inner children.
-__global__ __launch_bounds__(256) void k_level_split(const WorkItem* __restrict__ items, uint32_t count, uint32_t depth, int depthCap,
-                                                     uint32_t leafMax, const float4* __restrict__ segLo,
-                                                     const float4* __restrict__ segHi, uint32_t N2, const uint64_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ splitPos, uint32_t* __restrict__ innerCnt,
-                                                     uint32_t* __restrict__ subCnt, uint32_t subMax) {
-  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (w >= count) return;
-  const uint32_t b = items[w].b, e = items[w].e, n = e - b;
-  // a child at depth + 1 can hold at most leafMax << (depthCap - depth - 1) triangles
-  const int rem = depthCap - (int)depth - 1;
-  const uint64_t maxSide = rem >= 31 ? ~0ull : (uint64_t)leafMax << (rem < 0 ? 0 : rem);
-  const uint32_t kmin = (uint64_t)n > maxSide ? (uint32_t)(e - maxSide) : b + 1u;
-  const uint32_t kmax = (uint64_t)n > maxSide ? (uint32_t)(b + maxSide) : e - 1u;
-  const uint32_t kminC = kmin < b + 1u ? b + 1u : kmin, kmaxC = kmax > e - 1u ? e - 1u : kmax;
-  float cost = __int_as_float(0x7f800000);
-  uint32_t k = b + n / 2u;
-  auto sah = [&](uint32_t kk) {
-    const Box3 L = range_box(segLo, segHi, N2, b, kk), R = range_box(segLo, segHi, N2, kk, e);
-    const float nl = (float)((kk - b + leafMax - 1u) / leafMax), nr = (float)((e - kk + leafMax - 1u) / leafMax);
-    float c = half_area(L) * nl + half_area(R) * nr;
-    return c == c ? c : 3.0e38f;  // (NaN-proof: a degenerate box product)
-  };
-  auto lower_bound = [&](uint64_t key) {
-    uint32_t lo_ = b, hi_ = e;
-    while (lo_ < hi_) {
-      const uint32_t mid = lo_ + (hi_ - lo_) / 2u;
-      if (keys[mid] < key) lo_ = mid + 1u;
-      else hi_ = mid;
-    }
-    return lo_;
-  };
-  if (kminC <= kmaxC) {
-    const uint32_t span = kmaxC - kminC;  // candidates kminC .. kmaxC
-    if (span < 64u) {
-      // every position
-      if (lane <= span) k = kminC + lane, cost = sah(k);
-    } else {
-      // (a) evenly spaced positions; the last three lanes take the positions where the size
-      // class changes inside the range
-      k = kminC + (uint32_t)(((uint64_t)lane * span) / 63u);
-      if (lane >= 61u) {
-        const uint32_t kb = lower_bound((uint64_t)(lane - 60u) << 60);  // first key of class 1, 2, 3
-        if (kb >= kminC && kb <= kmaxC) k = kb;
-      }
-      cost = sah(k);
-      // (b) Morton-cell boundaries: a contiguous range of the curve that holds a sliver of the
-      // neighbouring cell has that cell's extent in its box, so the cuts that matter are the
-      // cell boundaries — the 63 places where the 6 key bits below the range's common prefix
-      // change (two octree levels; lane 32 is the classic LBVH split)
-      const uint64_t kf = keys[b], kl = keys[e - 1u];
-      if (kf != kl && lane >= 1u) {
-        const int hb = 63 - __clzll((long long)(kf ^ kl));  // highest differing bit
-        const int sh = hb >= 5 ? hb - 5 : 0;
-        const uint64_t prefix = hb >= 63 ? 0ull : (kf >> (hb + 1)) << (hb + 1);
-        const uint64_t sub = (uint64_t)lane << sh;
-        if (hb >= 5 || lane < (1u << (hb + 1))) {
-          const uint32_t kb = lower_bound(prefix | sub);
-          if (kb >= kminC && kb <= kmaxC) {
-            const float cb_ = sah(kb);
-            if (cb_ < cost || (cb_ == cost && kb < k)) cost = cb_, k = kb;
-          }
-        }
-      }
-    }
-  }
-  // wave-min of (cost, position): lowest position among equal costs
-  unsigned long long key = ((unsigned long long)__float_as_uint(cost) << 32) | k;  // costs are >= 0: bit order == value order
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(key, off, 64);
-    key = o < key ? o : key;
-  }
-  if (lane == 0) {
-    uint32_t kk = (uint32_t)key;
-    if ((uint32_t)(key >> 32) >= 0x7f800000u) kk = b + n / 2u;  // no finite candidate: the median always fits the budget
-    splitPos[w] = kk;
-    // children: leaves (<= leafMax), exact subtrees (<= subMax), or work items of the next level
-    const uint32_t n0 = kk - b, n1 = e - kk;
-    innerCnt[w] = (n0 > leafMax && n0 > subMax ? 1u : 0u) + (n1 > leafMax && n1 > subMax ? 1u : 0u);
-    subCnt[w] = (n0 > leafMax && n0 <= subMax ? 1u : 0u) + (n1 > leafMax && n1 <= subMax ? 1u : 0u);
-  }
-}
-
-// Write the node (packed + float form) and the next level's work items.
-__global__ void k_level_emit(const WorkItem* __restrict__ items, uint32_t count, uint32_t levelBase, uint32_t nextBase,
-                             const uint32_t* __restrict__ splitPos, const uint32_t* __restrict__ innerOff, uint32_t leafMax,
-                             const float4* __restrict__ segLo, const float4* __restrict__ segHi, uint32_t N2, float pad,
-                             float boxScale, uint4* __restrict__ nodes16, float4* __restrict__ nodesF, WorkItem* __restrict__ next,
-                             const uint32_t* __restrict__ subOff, uint32_t subBase, SubItem* __restrict__ subs, uint32_t subMax,
-                             uint32_t depth) {
-  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= count) return;
-  const uint32_t b = items[w].b, e = items[w].e, k = splitPos[w];
-  uint32_t slot = innerOff[w], sslot = subBase + subOff[w];
-  int32_t child[2];
-  const uint32_t cb[2] = {b, k}, ce[2] = {k, e};
-  Box3 B0 = range_box(segLo, segHi, N2, b, k), B1 = range_box(segLo, segHi, N2, k, e);
-  // child 0 = the smaller box (any-hit rays of the big-scene kernels enter it first: rt_kernels.hip Trav::round)
-  const bool swp = half_area(B1) < half_area(B0);
-  if (swp) {
-    const Box3 t = B0;
-    B0 = B1, B1 = t;
-  }
-  for (int c = 0; c < 2; ++c) {
-    const int o = swp ? 1 - c : c;  // the record's slot of range c
-    if (ce[c] - cb[c] > leafMax && ce[c] - cb[c] <= subMax) {
-      subs[sslot] = SubItem{cb[c], ce[c], depth + 1u, levelBase + w, (uint32_t)o};
-      child[o] = 0;  // (patched by k_sub_relocate once the subtree's root has its index)
-      ++sslot;
-    } else if (ce[c] - cb[c] > leafMax) {
-      next[slot] = WorkItem{cb[c], ce[c]};
-      child[o] = (int32_t)(nextBase + slot);
-      ++slot;
-    } else {
-      child[o] = ~(int32_t)((cb[c] << 3) | (ce[c] - cb[c] - 1u));
-    }
-  }
-  B0.lx -= pad, B0.ly -= pad, B0.lz -= pad, B0.hx += pad, B0.hy += pad, B0.hz += pad;
-  B1.lx -= pad, B1.ly -= pad, B1.lz -= pad, B1.hx += pad, B1.hy += pad, B1.hz += pad;
-  const uint32_t i = levelBase + w;
-  // float form (rtbvh::Node: lo0 hi0 lo1 hi1 child[2] pad[2])
-  nodesF[4 * (size_t)i + 0] = make_float4(B0.lx, B0.ly, B0.lz, B0.hx);
-  nodesF[4 * (size_t)i + 1] = make_float4(B0.hy, B0.hz, B1.lx, B1.ly);
-  nodesF[4 * (size_t)i + 2] = make_float4(B1.lz, B1.hx, B1.hy, B1.hz);
-  nodesF[4 * (size_t)i + 3] = make_float4(__int_as_float(child[0]), __int_as_float(child[1]), 0.f, 0.f);
-  // packed form (rtbvh::Node16: per child (lo, hi) pairs for x, y, z as binary16 of coordinate x boxScale, outward)
-  const float s = boxScale;
-  const uint32_t h[12] = {half_directed(B0.lx * s, false), half_directed(B0.hx * s, true), half_directed(B0.ly * s, false),
-                          half_directed(B0.hy * s, true),  half_directed(B0.lz * s, false), half_directed(B0.hz * s, true),
-                          half_directed(B1.lx * s, false), half_directed(B1.hx * s, true), half_directed(B1.ly * s, false),
-                          half_directed(B1.hy * s, true),  half_directed(B1.lz * s, false), half_directed(B1.hz * s, true)};
-  nodes16[2 * (size_t)i + 0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
-  nodes16[2 * (size_t)i + 1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, packed_ref(child[0]), packed_ref(child[1]));
 }
 
 // 48-B triangle records (rtbvh::TriRec): p0, e1 = p1 - p0, e2 = p2 - p0 (the float subtraction
@@ -856,6 +626,616 @@ static hipError_t rotate_and_pack(float4* nodesF, uint4* nodes16, uint32_t n, in
   return e;
 }
 
+// ---------------------------------------------------------------- the host builder's top on the device (round 4)
+// bvh_build.cpp's split() restated as kernels, rule for rule, for the ranges above the exact subtrees (more than kSubMax
+// triangles): binned SAH over the three centroid axes and the size axis (64 bins from 65,536 triangles, 16 below; the size
+// cut must win by 1.5 x) above 4,096 triangles, the exact sweep over the same four axes from there down, the depth budget
+// (`maxSide`), strict "<" in axis-then-position order.  What the host computes with min / max and counts (centroid bounds,
+// bins, boxes) does not depend on the order of the primitives, and its sorts use the total order (key, triangle id) — so the
+// SAME splits come out here, and with them the host builder's tree (tests/test_gpu_bvhbuild.py compares the two), in a few
+// milliseconds for a million triangles instead of the host's 35.  The host keeps what it alone can give bit for bit: the
+// size keys (libm's log2f; rtbvh::planSceneExact).  A range the host would split at its MEDIAN (no admissible SAH split:
+// coincident centroids, a spent depth budget) raises `needHost` and the caller takes the hybrid path (host top) instead.
+// One level of the tree per round of launches; the host keeps the list of ranges (a few thousand at most) and reads one
+// split position per range and level.
+constexpr uint32_t kTopChunk = 1024;   // primitives per workgroup of the per-level passes (256 threads x 4)
+constexpr uint32_t kSweepMaxD = 4096;  // bvh_build.cpp kSweepMax: ranges up to this are swept exactly
+constexpr int kKeyPosInf = 0x7f800000, kKeyNegInf = (int)0x807fffff;  // fkey(+inf), fkey(-inf)
+struct TopItem {
+  uint32_t b, e;    // range of `ord`
+  uint32_t blk0;    // its first workgroup in the level's grid
+  uint32_t nb;      // bins per axis (64 | 16); 0 = an exact-sweep range
+  uint32_t binIdx;  // which bin block (binned ranges), which sweep slot (swept ranges)
+  uint32_t node;    // its node's index
+  uint32_t pad0, pad1;
+};
+struct TopPrep {  // per range, from its centroid bounds: bin origin and scale per axis (axis 3 = the size key)
+  float lo[4], scale[4];
+  uint32_t use;  // bit a: axis a has extent
+  uint32_t pad[3];
+};
+struct TopDec {  // the chosen binned split
+  int axis, bin;
+  float lo, scale;
+};
+__device__ __forceinline__ float top_centroid(const float4& l, const float4& h, int a) {
+  return a == 0 ? 0.5f * l.x + 0.5f * h.x : a == 1 ? 0.5f * l.y + 0.5f * h.y : 0.5f * l.z + 0.5f * h.z;
+}
+__device__ __forceinline__ int top_bin(float c, float lo, float scale, int NB) {
+  const int k = (int)((c - lo) * scale);
+  return min(NB - 1, max(0, k));
+}
+// block-wide min / max of `cnt` ordered-int values per thread; the result is valid in thread 0
+template <int CNT>
+__device__ __forceinline__ void block_minmax(int* mn, int* mx, int* sh /* [2 * CNT * 4] */) {
+  for (int c = 0; c < CNT; ++c)
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[c] = min(mn[c], __shfl_xor(mn[c], off, 64));
+      mx[c] = max(mx[c], __shfl_xor(mx[c], off, 64));
+    }
+  const uint32_t w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0)
+    for (int c = 0; c < CNT; ++c) sh[(2 * c) * 4 + w] = mn[c], sh[(2 * c + 1) * 4 + w] = mx[c];
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int c = 0; c < CNT; ++c)
+      for (int k = 0; k < 4; ++k) mn[c] = min(mn[c], sh[(2 * c) * 4 + k]), mx[c] = max(mx[c], sh[(2 * c + 1) * 4 + k]);
+}
+
+__global__ void k_top_init(uint32_t count, int* __restrict__ ib, int* __restrict__ cbx) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count * 8u) ib[i] = (i & 7u) < 4u ? kKeyPosInf : kKeyNegInf;
+  if (i < count * 12u) cbx[i] = (i % 6u) < 3u ? kKeyPosInf : kKeyNegInf;
+}
+// centroid bounds and size-key range of every range (bvh_build.cpp split(): cb, sLo, sHi)
+__global__ __launch_bounds__(256) void k_top_bounds(const TopItem* __restrict__ items, const uint32_t* __restrict__ blkItem,
+                                                    const uint32_t* __restrict__ ord, const float4* __restrict__ lo,
+                                                    const float4* __restrict__ hi, const float* __restrict__ skey, int* __restrict__ ib) {
+  __shared__ int sh[32];
+  const uint32_t r = blkItem[blockIdx.x];
+  const TopItem it = items[r];
+  const uint32_t p0 = it.b + (blockIdx.x - it.blk0) * kTopChunk;
+  int mn[4] = {kKeyPosInf, kKeyPosInf, kKeyPosInf, kKeyPosInf}, mx[4] = {kKeyNegInf, kKeyNegInf, kKeyNegInf, kKeyNegInf};
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t p = p0 + threadIdx.x + 256u * e;
+    if (p < it.e) {
+      const uint32_t id = ord[p];
+      const float4 l = lo[id], h = hi[id];
+      const float v[4] = {top_centroid(l, h, 0), top_centroid(l, h, 1), top_centroid(l, h, 2), skey[id]};
+      for (int c = 0; c < 4; ++c) mn[c] = min(mn[c], fkey(v[c])), mx[c] = max(mx[c], fkey(v[c]));
+    }
+  }
+  block_minmax<4>(mn, mx, sh);
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 4; ++c) atomicMin(&ib[8 * r + c], mn[c]), atomicMax(&ib[8 * r + 4 + c], mx[c]);
+}
+__global__ void k_top_prep(const TopItem* __restrict__ items, uint32_t count, const int* __restrict__ ib, TopPrep* __restrict__ prep,
+                           int* __restrict__ bins) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  const TopItem it = items[r];
+  TopPrep P;
+  P.use = 0, P.pad[0] = P.pad[1] = P.pad[2] = 0;
+  const int NB = it.nb ? (int)it.nb : 1;
+  for (int a = 0; a < 4; ++a) {
+    const float l = funkey(ib[8 * r + a]), h = funkey(ib[8 * r + 4 + a]);
+    const float ext = h - l;
+    const bool use = ext > 0.f;
+    P.lo[a] = l, P.scale[a] = use ? NB / ext : 0.f;
+    P.use |= use ? 1u << a : 0u;
+  }
+  prep[r] = P;
+  if (it.nb) {  // its bins: empty boxes, no primitives
+    int* B = bins + (size_t)it.binIdx * 4u * 64u * 7u;
+    for (uint32_t k = 0; k < 4u * 64u; ++k) {
+      for (int c = 0; c < 3; ++c) B[7 * k + c] = kKeyPosInf, B[7 * k + 3 + c] = kKeyNegInf;
+      B[7 * k + 6] = 0;
+    }
+  }
+}
+// the bins of all four axes in one pass (LDS bins per workgroup, then merged: min / max and counts)
+__global__ __launch_bounds__(256) void k_top_bins(const TopItem* __restrict__ items, const uint32_t* __restrict__ blkItem,
+                                                  const uint32_t* __restrict__ ord, const float4* __restrict__ lo,
+                                                  const float4* __restrict__ hi, const float* __restrict__ skey,
+                                                  const TopPrep* __restrict__ prep, int* __restrict__ bins) {
+  __shared__ int sb[4 * 64 * 7];
+  const uint32_t r = blkItem[blockIdx.x];
+  const TopItem it = items[r];
+  if (it.nb == 0) return;
+  const int NB = (int)it.nb;
+  const TopPrep P = prep[r];
+  for (uint32_t k = threadIdx.x; k < 4u * 64u; k += 256u) {
+    for (int c = 0; c < 3; ++c) sb[7 * k + c] = kKeyPosInf, sb[7 * k + 3 + c] = kKeyNegInf;
+    sb[7 * k + 6] = 0;
+  }
+  __syncthreads();
+  const uint32_t p0 = it.b + (blockIdx.x - it.blk0) * kTopChunk;
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t p = p0 + threadIdx.x + 256u * e;
+    if (p < it.e) {
+      const uint32_t id = ord[p];
+      const float4 l = lo[id], h = hi[id];
+      const float v[4] = {top_centroid(l, h, 0), top_centroid(l, h, 1), top_centroid(l, h, 2), skey[id]};
+      const int bl[3] = {fkey(l.x), fkey(l.y), fkey(l.z)}, bh[3] = {fkey(h.x), fkey(h.y), fkey(h.z)};
+      for (int a = 0; a < 4; ++a) {
+        if (!((P.use >> a) & 1u)) continue;
+        int* B = sb + 7 * (a * 64 + top_bin(v[a], P.lo[a], P.scale[a], NB));
+        for (int c = 0; c < 3; ++c) atomicMin(&B[c], bl[c]), atomicMax(&B[3 + c], bh[c]);
+        atomicAdd(&B[6], 1);
+      }
+    }
+  }
+  __syncthreads();
+  int* G = bins + (size_t)it.binIdx * 4u * 64u * 7u;
+  for (uint32_t k = threadIdx.x; k < 4u * 64u; k += 256u) {
+    const int cnt = sb[7 * k + 6];
+    if (cnt) {
+      for (int c = 0; c < 3; ++c) atomicMin(&G[7 * k + c], sb[7 * k + c]), atomicMax(&G[7 * k + 3 + c], sb[7 * k + 3 + c]);
+      atomicAdd(&G[7 * k + 6], cnt);
+    }
+  }
+}
+__device__ __forceinline__ Box3 top_box_of(const int* B) {
+  return Box3{funkey(B[0]), funkey(B[1]), funkey(B[2]), funkey(B[3]), funkey(B[4]), funkey(B[5])};
+}
+// the binned SAH choice of bvh_build.cpp split(), one thread per range (a few hundred operations)
+__global__ void k_top_choose(const TopItem* __restrict__ items, uint32_t count, uint32_t depth, int depthCap, uint32_t leafMax,
+                             const TopPrep* __restrict__ prep, const int* __restrict__ bins, TopDec* __restrict__ dec,
+                             uint32_t* __restrict__ mid, uint32_t* __restrict__ needHost) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  const TopItem it = items[r];
+  if (it.nb == 0) return;
+  const int NB = (int)it.nb;
+  const uint32_t n = it.e - it.b;
+  const TopPrep P = prep[r];
+  const int rem = depthCap - (int)depth - 1;
+  const unsigned long long maxSide = rem >= 31 ? ~0ull : (unsigned long long)leafMax << (rem < 0 ? 0 : rem);
+  const int* G = bins + (size_t)it.binIdx * 4u * 64u * 7u;
+  const float inf = __int_as_float(0x7f800000);
+  float bestCost = inf;
+  int bestAxis = -1, bestBin = -1;
+  uint32_t bestLeft = 0;
+  for (int ax = 0; ax < 4; ++ax) {
+    if (!((P.use >> ax) & 1u)) continue;
+    const int* A = G + 7 * (ax * 64);
+    float rightArea[64];
+    uint32_t rightCnt[64];
+    Box3 acc{inf, inf, inf, -inf, -inf, -inf};
+    uint32_t c = 0;
+    for (int k = NB - 1; k > 0; --k) {
+      acc = rot_union(acc, top_box_of(A + 7 * k)), c += (uint32_t)A[7 * k + 6];
+      rightArea[k] = half_area(acc), rightCnt[k] = c;
+    }
+    acc = Box3{inf, inf, inf, -inf, -inf, -inf}, c = 0;
+    for (int k = 0; k < NB - 1; ++k) {
+      acc = rot_union(acc, top_box_of(A + 7 * k)), c += (uint32_t)A[7 * k + 6];
+      if (c == 0 || rightCnt[k + 1] == 0 || c > maxSide || rightCnt[k + 1] > maxSide) continue;
+      float cost = half_area(acc) * ceilf(c / (float)leafMax) + rightArea[k + 1] * ceilf(rightCnt[k + 1] / (float)leafMax);
+      if (ax == 3) cost *= 1.5f;  // (bvh_build.cpp sizeBias)
+      if (cost < bestCost) bestCost = cost, bestAxis = ax, bestBin = k, bestLeft = c;
+    }
+  }
+  // the host's median fall-backs: no admissible cut, or an extremely lopsided one deep in the tree
+  const uint32_t small = bestLeft < n - bestLeft ? bestLeft : n - bestLeft;
+  if (bestAxis < 0 || (n > 64u && (unsigned long long)small * 64ull < n && (int)depth > rtbvh::kMaxDepth / 2)) {
+    atomicExch(needHost, 1u);
+    dec[r] = TopDec{-1, 0, 0.f, 0.f}, mid[r] = it.b + n / 2u;
+    return;
+  }
+  dec[r] = TopDec{bestAxis, bestBin, P.lo[bestAxis], P.scale[bestAxis]};
+  mid[r] = it.b + bestLeft;
+}
+__device__ __forceinline__ bool top_goes_left(const TopDec& D, int NB, uint32_t id, const float4* lo, const float4* hi, const float* skey) {
+  const float v = D.axis == 3 ? skey[id] : top_centroid(lo[id], hi[id], D.axis);
+  return top_bin(v, D.lo, D.scale, NB) <= D.bin;
+}
+// stable partition of the binned ranges, three passes: lefts per workgroup, their prefix per range, the move
+__global__ __launch_bounds__(256) void k_top_count(const TopItem* __restrict__ items, const uint32_t* __restrict__ blkItem,
+                                                   const uint32_t* __restrict__ ord, const float4* __restrict__ lo,
+                                                   const float4* __restrict__ hi, const float* __restrict__ skey,
+                                                   const TopDec* __restrict__ dec, uint32_t* __restrict__ blockLeft) {
+  __shared__ uint32_t sh[4];
+  const uint32_t r = blkItem[blockIdx.x];
+  const TopItem it = items[r];
+  if (it.nb == 0) return;
+  const TopDec D = dec[r];
+  const uint32_t p0 = it.b + (blockIdx.x - it.blk0) * kTopChunk;
+  uint32_t c = 0;
+  if (D.axis >= 0)
+    for (uint32_t e = 0; e < 4u; ++e) {
+      const uint32_t p = p0 + threadIdx.x + 256u * e;
+      if (p < it.e) c += top_goes_left(D, (int)it.nb, ord[p], lo, hi, skey) ? 1u : 0u;
+    }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blockLeft[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// one wave per range: exclusive prefix of its workgroups' counts (in place)
+__global__ __launch_bounds__(64) void k_top_offsets(const TopItem* __restrict__ items, uint32_t* __restrict__ blockLeft) {
+  const TopItem it = items[blockIdx.x];
+  if (it.nb == 0) return;
+  const uint32_t nBlk = (it.e - it.b + kTopChunk - 1u) / kTopChunk, lane = threadIdx.x;
+  uint32_t base = 0;
+  for (uint32_t k0 = 0; k0 < nBlk; k0 += 64u) {
+    const uint32_t k = k0 + lane;
+    const uint32_t v = k < nBlk ? blockLeft[it.blk0 + k] : 0u;
+    uint32_t s = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(s, off, 64);
+      if ((int)lane >= off) s += o;
+    }
+    if (k < nBlk) blockLeft[it.blk0 + k] = base + s - v;
+    base += __shfl(s, 63, 64);
+  }
+}
+__global__ __launch_bounds__(256) void k_top_scatter(const TopItem* __restrict__ items, const uint32_t* __restrict__ blkItem,
+                                                     const uint32_t* __restrict__ ord, const float4* __restrict__ lo,
+                                                     const float4* __restrict__ hi, const float* __restrict__ skey,
+                                                     const TopDec* __restrict__ dec, const uint32_t* __restrict__ mid,
+                                                     const uint32_t* __restrict__ blockLeft, uint32_t* __restrict__ tmp) {
+  __shared__ uint32_t sh[4];
+  const uint32_t r = blkItem[blockIdx.x];
+  const TopItem it = items[r];
+  if (it.nb == 0) return;
+  const TopDec D = dec[r];
+  const uint32_t p0 = it.b + (blockIdx.x - it.blk0) * kTopChunk;
+  // thread t owns the four consecutive positions p0 + 4 t ... (the partition is stable)
+  uint32_t id[4];
+  bool left[4];
+  uint32_t c = 0;
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t p = p0 + 4u * threadIdx.x + e;
+    id[e] = p < it.e ? ord[p] : 0u;
+    left[e] = p < it.e && D.axis >= 0 && top_goes_left(D, (int)it.nb, id[e], lo, hi, skey);
+    c += left[e] ? 1u : 0u;
+  }
+  uint32_t s = c;  // inclusive scan over the workgroup's threads
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(s, off, 64);
+    if ((int)lane >= off) s += o;
+  }
+  if (lane == 63u) sh[w] = s;
+  __syncthreads();
+  uint32_t before = s - c;
+  for (uint32_t k = 0; k < w; ++k) before += sh[k];
+  if (D.axis < 0) {  // (no decision: the range stays as it is)
+    for (uint32_t e = 0; e < 4u; ++e) {
+      const uint32_t p = p0 + 4u * threadIdx.x + e;
+      if (p < it.e) tmp[p] = id[e];
+    }
+    return;
+  }
+  const uint32_t leftBase = it.b + blockLeft[blockIdx.x];
+  // rights before this workgroup's chunk = elements before it minus lefts before it
+  const uint32_t rightBase = mid[r] + (p0 - it.b) - blockLeft[blockIdx.x];
+  uint32_t l = before, rgt = 4u * threadIdx.x - before;
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t p = p0 + 4u * threadIdx.x + e;
+    if (p >= it.e) break;
+    if (left[e]) tmp[leftBase + l++] = id[e];
+    else tmp[rightBase + rgt++] = id[e];
+  }
+}
+__global__ __launch_bounds__(256) void k_top_copyback(const TopItem* __restrict__ items, const uint32_t* __restrict__ blkItem,
+                                                      const uint32_t* __restrict__ tmp, uint32_t* __restrict__ ord) {
+  const uint32_t r = blkItem[blockIdx.x];
+  const TopItem it = items[r];
+  if (it.nb == 0) return;
+  const uint32_t p0 = it.b + (blockIdx.x - it.blk0) * kTopChunk;
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t p = p0 + threadIdx.x + 256u * e;
+    if (p < it.e) ord[p] = tmp[p];
+  }
+}
+
+// The exact sweep of bvh_build.cpp split() for one range of 1,025 ... 4,096 primitives per workgroup of 1,024 threads (four
+// elements each): the range in ascending triangle id (so that a position stands for the id in the sort keys), then per axis a
+// bitonic sort by (key, id), suffix areas, prefix boxes, the cost of every cut, the cheapest — lowest axis, then lowest
+// position, among equal costs — and the range rewritten in the best axis' order.
+constexpr uint32_t kSweepT = 1024, kSweepN = 4096;
+constexpr size_t kSweepLds = (size_t)kSweepN * (8 + 24 + 4 + 2) + 64;
+__device__ __forceinline__ void sweep_sort(unsigned long long* key) {
+  for (uint32_t k = 2; k <= kSweepN; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t e = 0; e < 2u; ++e) {
+        const uint32_t p = threadIdx.x + kSweepT * e;          // pair index 0 .. 2047
+        const uint32_t i = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)), x = i | j;
+        const unsigned long long ka = key[i], kb = key[x];
+        const bool up = (i & k) == 0;
+        if ((ka > kb) == up) key[i] = kb, key[x] = ka;
+      }
+      __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_top_sweep(const TopItem* __restrict__ items, const uint32_t* __restrict__ sweepList,
+                                                    uint32_t depth, int depthCap, uint32_t leafMax, const int* __restrict__ ib,
+                                                    const float4* __restrict__ lo, const float4* __restrict__ hi,
+                                                    const float* __restrict__ skey, uint32_t* __restrict__ ord, uint32_t* __restrict__ tmp,
+                                                    uint32_t* __restrict__ mid, uint32_t* __restrict__ needHost) {
+  extern __shared__ unsigned long long sweep_lds[];
+  unsigned long long* key = sweep_lds;                          // [4096] sort keys
+  float* sc = reinterpret_cast<float*>(key + kSweepN);          // [6][4096] boxes in sorted order / their scans
+  float* sufA = sc + 6 * kSweepN;                               // [4096] area of the sorted suffix [i, n)
+  uint16_t* bestPos = reinterpret_cast<uint16_t*>(sufA + kSweepN);  // [4096] home positions in the best axis' order
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(bestPos + kSweepN);  // cost bits << 32 | axis << 16 | left count
+  const uint32_t r = sweepList[blockIdx.x];
+  const TopItem it = items[r];
+  const uint32_t n = it.e - it.b, t = threadIdx.x;
+  const float inf = __int_as_float(0x7f800000);
+  // home order = ascending triangle id
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t j = t + kSweepT * e;
+    key[j] = j < n ? (unsigned long long)ord[it.b + j] : ~0ull;
+  }
+  if (t == 0) *best = ~0ull;
+  __syncthreads();
+  sweep_sort(key);
+  uint32_t* home = tmp + it.b;  // (the range's slice of the second buffer: nobody else's)
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t j = t + kSweepT * e;
+    if (j < n) home[j] = (uint32_t)key[j];
+  }
+  __syncthreads();
+  const int rem = depthCap - (int)depth - 1;
+  const unsigned long long maxSide = rem >= 31 ? ~0ull : (unsigned long long)leafMax << (rem < 0 ? 0 : rem);
+  const float sLo = funkey(ib[8 * r + 3]), sHi = funkey(ib[8 * r + 7]);
+  auto gather = [&]() {
+    for (uint32_t e = 0; e < 4u; ++e) {
+      const uint32_t i = t + kSweepT * e;
+      if (i < n) {
+        const uint32_t id = home[(uint32_t)(key[i] & 4095u)];
+        const float4 l = lo[id], h = hi[id];
+        sc[i] = l.x, sc[kSweepN + i] = l.y, sc[2 * kSweepN + i] = l.z, sc[3 * kSweepN + i] = h.x, sc[4 * kSweepN + i] = h.y, sc[5 * kSweepN + i] = h.z;
+      } else {
+        sc[i] = sc[kSweepN + i] = sc[2 * kSweepN + i] = inf, sc[3 * kSweepN + i] = sc[4 * kSweepN + i] = sc[5 * kSweepN + i] = -inf;
+      }
+    }
+    __syncthreads();
+  };
+  auto scan = [&](bool suffix) {  // inclusive scan (union of boxes) over the sorted positions
+    for (uint32_t d = 1; d < kSweepN; d <<= 1) {
+      float v[4][6];
+      for (uint32_t e = 0; e < 4u; ++e) {
+        const uint32_t i = t + kSweepT * e;
+        const bool take = suffix ? i + d < kSweepN : i >= d;
+        const uint32_t j = suffix ? i + d : i - d;
+        for (int c = 0; c < 6; ++c) v[e][c] = sc[c * kSweepN + i];
+        if (take)
+          for (int c = 0; c < 3; ++c) v[e][c] = fminf(v[e][c], sc[c * kSweepN + j]), v[e][3 + c] = fmaxf(v[e][3 + c], sc[(3 + c) * kSweepN + j]);
+      }
+      __syncthreads();
+      for (uint32_t e = 0; e < 4u; ++e) {
+        const uint32_t i = t + kSweepT * e;
+        for (int c = 0; c < 6; ++c) sc[c * kSweepN + i] = v[e][c];
+      }
+      __syncthreads();
+    }
+  };
+  auto area_at = [&](uint32_t j) {
+    const float dx = sc[3 * kSweepN + j] - sc[j], dy = sc[4 * kSweepN + j] - sc[kSweepN + j], dz = sc[5 * kSweepN + j] - sc[2 * kSweepN + j];
+    return dx < 0.f ? 0.f : dx * dy + dy * dz + dz * dx;
+  };
+  for (int ax = 0; ax < 4; ++ax) {
+    if (ax == 3 && !(sHi > sLo)) continue;  // (wave-uniform: every thread reads the same bounds)
+    for (uint32_t e = 0; e < 4u; ++e) {
+      const uint32_t j = t + kSweepT * e;
+      if (j < n) {
+        const uint32_t id = home[j];
+        const float v = ax == 3 ? skey[id] : top_centroid(lo[id], hi[id], ax);
+        key[j] = ((unsigned long long)((uint32_t)fkey(v) ^ 0x80000000u) << 12) | j;
+      } else {
+        key[j] = ~0ull;
+      }
+    }
+    __syncthreads();
+    sweep_sort(key);
+    gather();
+    scan(true);
+    for (uint32_t e = 0; e < 4u; ++e) {
+      const uint32_t i = t + kSweepT * e;
+      sufA[i] = area_at(i);
+    }
+    __syncthreads();
+    gather();
+    scan(false);
+    const unsigned long long before = *best;
+    __syncthreads();
+    for (uint32_t e = 0; e < 4u; ++e) {
+      const uint32_t i = t + kSweepT * e;  // the cut behind sorted position i: i + 1 elements on the left
+      if (i + 1u < n) {
+        const uint32_t nl = i + 1u, nr = n - nl;
+        if (nl <= maxSide && nr <= maxSide) {
+          float cost = area_at(i) * ceilf(nl / (float)leafMax) + sufA[i + 1u] * ceilf(nr / (float)leafMax);
+          if (ax == 3) cost *= 1.5f;
+          if (cost == cost && cost >= 0.f && cost < inf)
+            atomicMin(best, ((unsigned long long)__float_as_uint(cost) << 32) | ((unsigned long long)ax << 16) | nl);
+        }
+      }
+    }
+    __syncthreads();
+    if (*best != before)  // this axis holds the best cut so far: keep its order
+      for (uint32_t e = 0; e < 4u; ++e) {
+        const uint32_t i = t + kSweepT * e;
+        bestPos[i] = (uint16_t)(key[i] & 4095u);
+      }
+    __syncthreads();
+  }
+  const unsigned long long bb = *best;
+  if (bb == ~0ull) {  // the host would split at the median
+    if (t == 0) atomicExch(needHost, 1u), mid[r] = it.b + n / 2u;
+    return;
+  }
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t i = t + kSweepT * e;
+    if (i < n) ord[it.b + i] = home[bestPos[i]];
+  }
+  if (t == 0) mid[r] = it.b + (uint32_t)(bb & 0xffffu);
+}
+
+// boxes of the two children of every split range
+__global__ __launch_bounds__(256) void k_top_childbox(const TopItem* __restrict__ items, const uint32_t* __restrict__ blkItem,
+                                                      const uint32_t* __restrict__ ord, const float4* __restrict__ lo,
+                                                      const float4* __restrict__ hi, const uint32_t* __restrict__ mid, int* __restrict__ cbx) {
+  __shared__ int sh[48];
+  const uint32_t r = blkItem[blockIdx.x];
+  const TopItem it = items[r];
+  const uint32_t p0 = it.b + (blockIdx.x - it.blk0) * kTopChunk, m = mid[r];
+  int mn[6], mx[6];  // [side * 3 + axis]
+  for (int c = 0; c < 6; ++c) mn[c] = kKeyPosInf, mx[c] = kKeyNegInf;
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t p = p0 + threadIdx.x + 256u * e;
+    if (p < it.e) {
+      const uint32_t id = ord[p];
+      const float4 l = lo[id], h = hi[id];
+      const int s = p >= m ? 3 : 0;
+      mn[s] = min(mn[s], fkey(l.x)), mn[s + 1] = min(mn[s + 1], fkey(l.y)), mn[s + 2] = min(mn[s + 2], fkey(l.z));
+      mx[s] = max(mx[s], fkey(h.x)), mx[s + 1] = max(mx[s + 1], fkey(h.y)), mx[s + 2] = max(mx[s + 2], fkey(h.z));
+    }
+  }
+  block_minmax<6>(mn, mx, sh);
+  if (threadIdx.x == 0)
+    for (int s = 0; s < 2; ++s)
+      for (int a = 0; a < 3; ++a) atomicMin(&cbx[12 * r + 6 * s + a], mn[3 * s + a]), atomicMax(&cbx[12 * r + 6 * s + 3 + a], mx[3 * s + a]);
+}
+// the node record of every split range (padded child boxes, the smaller box in slot 0 as bvh_build.cpp smallerChildFirst
+// leaves it), its parts registered for k_subtree, its leaves put in ascending id
+__global__ void k_top_emit(const TopItem* __restrict__ items, uint32_t count, uint32_t depth, const uint32_t* __restrict__ mid,
+                           const int32_t* __restrict__ refs, const int* __restrict__ cbx, float pad, uint32_t* __restrict__ ord,
+                           RNode* __restrict__ nodes, SubItem* __restrict__ subs) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  const TopItem it = items[r];
+  const uint32_t m = mid[r];
+  Box3 B[2];
+  for (int s = 0; s < 2; ++s) {
+    B[s] = top_box_of(cbx + 12 * r + 6 * s);
+    B[s].lx -= pad, B[s].ly -= pad, B[s].lz -= pad, B[s].hx += pad, B[s].hy += pad, B[s].hz += pad;
+  }
+  const bool swp = half_area(B[1]) < half_area(B[0]);
+  RNode N;
+  N.pad[0] = N.pad[1] = 0;
+  for (int s = 0; s < 2; ++s) {
+    const int slot = swp ? 1 - s : s;
+    const uint32_t cb = s ? m : it.b, ce = s ? it.e : m;
+    int32_t ref = refs[2 * r + s];
+    if (ref < 0 && ((~(uint32_t)ref) & rtbvh::kPartFlag)) {
+      subs[(~(uint32_t)ref) & (rtbvh::kPartFlag - 1u)] = SubItem{cb, ce, depth + 1u, it.node, (uint32_t)slot};
+      ref = 0;  // (patched by k_sub_relocate once the subtree's root has its index)
+    } else if (ref < 0) {
+      for (uint32_t x = cb + 1u; x < ce; ++x) {  // a leaf of the top: ascending triangle id, as the host leaves it
+        const uint32_t v = ord[x];
+        uint32_t y = x;
+        while (y > cb && ord[y - 1u] > v) ord[y] = ord[y - 1u], --y;
+        ord[y] = v;
+      }
+    }
+    rot_set(N, slot, ref, B[s]);
+  }
+  nodes[it.node] = N;
+}
+__global__ void k_iota(uint32_t* __restrict__ v, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+// dynamic LDS beyond 64 KiB is granted per kernel AND per device (one process may build on several devices: rt_group)
+static hipError_t grant_lds(const void* fn, size_t bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = -1;
+  if (dev >= 0 && (done.load() & (1ull << dev))) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && dev >= 0) done.fetch_or(1ull << dev);
+  return e;
+}
+
+// One allocation cut into the builder's temporaries (two dozen hipMalloc / hipFree pairs cost 2-3 ms of a 20-ms build).
+struct Arena {
+  char* base = nullptr;
+  size_t size = 0, used = 0;
+  size_t reserve(size_t bytes) {
+    const size_t at = size;
+    size += (bytes + 255u) & ~(size_t)255u;
+    return at;
+  }
+  hipError_t commit() { return hipMalloc((void**)&base, size ? size : 256); }
+  template <class T>
+  T* at(size_t off) const { return reinterpret_cast<T*>(base + off); }
+  void release() {
+    if (base) (void)hipFree(base);
+    base = nullptr;
+  }
+};
+
+// The part of a build below a finished top: nodesF[0, nTop) hold the top's float records (part refs still 0), nodes16 the
+// same packed, `subs` the parts; builds every part's exact subtree, numbers them behind the top, runs the rotation passes
+// and the final numbering / packing, and writes the triangle records.  Outputs as gpu_bvh_build.
+static hipError_t subtrees_and_finish(const float* dVpos, const uint4* dTriShade, uint32_t n, uint32_t nTop, uint32_t nSub,
+                                      const SubItem* subs, uint32_t* order, const float4* lo, const float4* hi, uint32_t leafMax,
+                                      int depthCap, float pad, float boxScale, uint32_t topMaxDepth, uint32_t maxNodes, float4* nodesF,
+                                      uint4* nodes16, float4* tris, float4* trisRef, uint32_t* nTotalOut, uint32_t* maxDepthOut,
+                                      hipStream_t stream) {
+  Arena A;
+  const size_t nS = nSub ? nSub : 1u;
+  size_t scanBytes = 0;
+  hipError_t e = rocprim::exclusive_scan(nullptr, scanBytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, nS, rocprim::plus<uint32_t>(), stream);
+  if (e != hipSuccess) return e;
+  const size_t oSizes = A.reserve(nS * 4), oScratchOff = A.reserve(nS * 4), oSubNodes = A.reserve(nS * 4), oFinalOff = A.reserve(nS * 4),
+               oHeight = A.reserve(4), oTmp = A.reserve(scanBytes ? scanBytes : 16), oScratch = A.reserve(4 * (size_t)n * sizeof(float4));
+  if ((e = A.commit()) != hipSuccess) return e;
+  uint32_t *subSizes = A.at<uint32_t>(oSizes), *scratchOff = A.at<uint32_t>(oScratchOff), *subNodes = A.at<uint32_t>(oSubNodes),
+           *finalOff = A.at<uint32_t>(oFinalOff), *height = A.at<uint32_t>(oHeight);
+  void* tmp = A.at<void>(oTmp);
+  float4* scratch = A.at<float4>(oScratch);
+#define SF_TRY(expr)        \
+  do {                      \
+    e = (expr);             \
+    if (e != hipSuccess) {  \
+      A.release();          \
+      return e;             \
+    }                       \
+  } while (0)
+  const dim3 blk(256), grdN((n + 255) / 256);
+  uint32_t nTotal = nTop, maxDepth = topMaxDepth;
+  SF_TRY(hipMemsetAsync(height, 0, sizeof(uint32_t), stream));
+  if (nSub) {
+    hipLaunchKernelGGL(k_sub_sizes, dim3((nSub + 255) / 256), blk, 0, stream, subs, nSub, subSizes);
+    SF_TRY(rocprim::exclusive_scan(tmp, scanBytes, subSizes, scratchOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
+    const size_t ldsBytes = subtree_lds_bytes((int)kSubMax);
+    static std::atomic<unsigned long long> ldsSet{0};
+    SF_TRY(grant_lds(reinterpret_cast<const void*>(&k_subtree<(int)kSubMax>), ldsBytes, ldsSet));
+    hipLaunchKernelGGL((k_subtree<(int)kSubMax>), dim3(nSub), dim3(kSubMax), ldsBytes, stream, subs, scratchOff, order, lo, hi, leafMax,
+                       depthCap, scratch, subNodes, height);
+    SF_TRY(rocprim::exclusive_scan(tmp, scanBytes, subNodes, finalOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(k_sub_relocate, dim3(nSub), blk, 0, stream, subs, scratchOff, subNodes, finalOff, nTop, scratch, pad, boxScale,
+                       nodes16, nodesF);
+    uint32_t lastOff = 0, lastCnt = 0, h = 0;
+    SF_TRY(hipMemcpyAsync(&lastOff, finalOff + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
+    SF_TRY(hipMemcpyAsync(&lastCnt, subNodes + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
+    SF_TRY(hipMemcpyAsync(&h, height, 4, hipMemcpyDeviceToHost, stream));
+    SF_TRY(hipStreamSynchronize(stream));
+    nTotal = nTop + lastOff + lastCnt;
+    maxDepth = maxDepth > h ? maxDepth : h;
+    if (nTotal > maxNodes) {
+      A.release();
+      return hipErrorInvalidValue;
+    }
+  }
+  // rotation passes over the whole tree (as the host builder's: 3 on big scenes, 8 on small ones)
+  SF_TRY(rotate_and_pack(nodesF, nodes16, nTotal, depthCap, boxScale, n > 200000u ? 3 : 8, &maxDepth, stream));
+  // triangle records in the FINAL leaf order (the exact builder has reordered its ranges), and in reference order
+  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
+  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
+  SF_TRY(hipStreamSynchronize(stream));
+  SF_TRY(hipGetLastError());
+#undef SF_TRY
+  A.release();
+  *nTotalOut = nTotal, *maxDepthOut = maxDepth;
+  return hipSuccess;
+}
+
 #define GB_TRY(expr)            \
   do {                          \
     hipError_t e_ = (expr);     \
@@ -866,170 +1246,6 @@ static hipError_t rotate_and_pack(float4* nodesF, uint4* nodes16, uint32_t n, in
   } while (0)
 
 }  // namespace
-
-// Builds nodes16 / nodesF / tris / trisRef on the current device.  The output arrays are
-// hipMalloc'ed here and owned by the caller.  Returns hipSuccess and fills `out`.
-hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n, const rtbvh::ScenePlan& P, GpuBvh* out,
-                         hipStream_t stream) {
-  *out = GpuBvh{};
-  const uint32_t leafMax = P.leafMax;
-  uint32_t N2 = 1;
-  while (N2 < n) N2 <<= 1;
-  float4 *lo = nullptr, *hi = nullptr, *segLo = nullptr, *segHi = nullptr, *nodesF = nullptr, *tris = nullptr, *trisRef = nullptr;
-  uint4* nodes16 = nullptr;
-  int* cb = nullptr;
-  uint64_t *keys = nullptr, *keys2 = nullptr;
-  uint32_t *vals = nullptr, *order = nullptr, *splitPos = nullptr, *innerCnt = nullptr, *innerOff = nullptr;
-  WorkItem *itemsA = nullptr, *itemsB = nullptr;
-  SubItem* subs = nullptr;
-  uint32_t *subCnt = nullptr, *subOff = nullptr, *subSizes = nullptr, *scratchOff = nullptr, *subNodes = nullptr, *finalOff = nullptr,
-           *height = nullptr;
-  float4* scratch = nullptr;
-  void* tmp = nullptr;
-  bool keepOutputs = false;
-  static const uint32_t subMax = getenv("RT_BVH_GPU_SUB") ? (uint32_t)atoi(getenv("RT_BVH_GPU_SUB")) : kSubMax;  // 0: Morton cuts all the way down
-  // the top of the tree (ranges above subMax): the cheapest cut of the static Morton order.  (Round 3 also had the host's
-  // binned SAH as a device kernel here: worse trees under 1,024-triangle subtrees and 3 x the time,
-  // profiles/r03_device_bvh_top_variants.txt; round 4's hybrid builder — gpu_bvh_build_over_top below — takes the host's
-  // OWN top instead.)
-  auto cleanup = [&]() {
-    for (void* p : {(void*)lo, (void*)hi, (void*)segLo, (void*)segHi, (void*)cb, (void*)keys, (void*)keys2, (void*)vals, (void*)order,
-                    (void*)splitPos, (void*)innerCnt, (void*)innerOff, (void*)itemsA, (void*)itemsB, (void*)subs, (void*)subCnt,
-                    (void*)subOff, (void*)subSizes, (void*)scratchOff, (void*)subNodes, (void*)finalOff, (void*)height, (void*)scratch,
-                    tmp})
-      if (p) (void)hipFree(p);
-    if (!keepOutputs)
-      for (void* p : {(void*)nodes16, (void*)nodesF, (void*)tris, (void*)trisRef})
-        if (p) (void)hipFree(p);
-  };
-  const uint32_t maxNodes = n;  // a binary tree over n > leafMax triangles with >= 1 per leaf has < n inner nodes
-  GB_TRY(hipMalloc((void**)&lo, (size_t)n * sizeof(float4)));
-  GB_TRY(hipMalloc((void**)&hi, (size_t)n * sizeof(float4)));
-  GB_TRY(hipMalloc((void**)&segLo, 2 * (size_t)N2 * sizeof(float4)));
-  GB_TRY(hipMalloc((void**)&segHi, 2 * (size_t)N2 * sizeof(float4)));
-  GB_TRY(hipMalloc((void**)&cb, 6 * sizeof(int)));
-  GB_TRY(hipMalloc((void**)&keys, (size_t)n * sizeof(uint64_t)));
-  GB_TRY(hipMalloc((void**)&keys2, (size_t)n * sizeof(uint64_t)));
-  GB_TRY(hipMalloc((void**)&vals, (size_t)n * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&order, (size_t)n * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&splitPos, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&innerCnt, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&innerOff, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&itemsA, (size_t)maxNodes * sizeof(WorkItem)));
-  GB_TRY(hipMalloc((void**)&itemsB, (size_t)maxNodes * sizeof(WorkItem)));
-  GB_TRY(hipMalloc((void**)&subs, (size_t)maxNodes * sizeof(SubItem)));
-  GB_TRY(hipMalloc((void**)&subCnt, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&subOff, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&subSizes, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&scratchOff, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&subNodes, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&finalOff, (size_t)maxNodes * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&height, sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&scratch, 4 * (size_t)maxNodes * sizeof(float4)));
-  GB_TRY(hipMemsetAsync(height, 0, sizeof(uint32_t), stream));
-  GB_TRY(hipMalloc((void**)&nodes16, 2 * (size_t)maxNodes * sizeof(uint4)));
-  GB_TRY(hipMalloc((void**)&nodesF, 4 * (size_t)maxNodes * sizeof(float4)));
-  GB_TRY(hipMalloc((void**)&tris, 3 * (size_t)n * sizeof(float4)));
-  GB_TRY(hipMalloc((void**)&trisRef, 3 * (size_t)n * sizeof(float4)));
-  size_t sortBytes = 0, scanBytes = 0;
-  GB_TRY(rocprim::radix_sort_pairs(nullptr, sortBytes, keys, keys2, vals, order, n, 0, 63, stream));
-  GB_TRY(rocprim::exclusive_scan(nullptr, scanBytes, innerCnt, innerOff, 0u, (size_t)maxNodes, rocprim::plus<uint32_t>(), stream));
-  const size_t tmpBytes = sortBytes > scanBytes ? sortBytes : scanBytes;
-  GB_TRY(hipMalloc(&tmp, tmpBytes ? tmpBytes : 16));
-
-  const dim3 blk(256), grdN((n + 255) / 256);
-  hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, cb);
-  hipLaunchKernelGGL(k_tri_boxes, grdN, blk, 0, stream, dVpos, dTriShade, n, lo, hi, cb);
-  hipLaunchKernelGGL(k_morton, grdN, blk, 0, stream, lo, hi, n, cb, keys, vals);
-  GB_TRY(rocprim::radix_sort_pairs(tmp, sortBytes, keys, keys2, vals, order, n, 0, 63, stream));
-  hipLaunchKernelGGL(k_seg_leaves, dim3((N2 + 255) / 256), blk, 0, stream, lo, hi, order, n, N2, segLo, segHi);
-  for (uint32_t cnt = N2 / 2; cnt >= 1; cnt >>= 1)  // level with `cnt` nodes starts at index cnt
-    hipLaunchKernelGGL(k_seg_level, dim3((cnt + 255) / 256), blk, 0, stream, cnt, cnt, segLo, segHi);
-  // top-down, one level at a time; ranges of <= subMax triangles become items of the exact builder
-  const WorkItem root{0u, n};
-  GB_TRY(hipMemcpyAsync(itemsA, &root, sizeof root, hipMemcpyHostToDevice, stream));
-  uint32_t count = 1, levelBase = 0, depth = 0, maxDepth = 0, nSub = 0;
-  if (n <= subMax) {  // the whole scene is one exact subtree
-    const SubItem whole{0u, n, 0u, ~0u, 0u};
-    GB_TRY(hipMemcpyAsync(subs, &whole, sizeof whole, hipMemcpyHostToDevice, stream));
-    nSub = 1, count = 0;
-  }
-  WorkItem *cur = itemsA, *nxt = itemsB;
-  while (count) {
-    if ((int)depth >= rtbvh::kMaxDepth - 1 || levelBase + count > maxNodes) {
-      cleanup();
-      return hipErrorInvalidValue;  // (cannot happen: the depth budget is enforced by the split choice)
-    }
-    hipLaunchKernelGGL(k_level_split, dim3((count + 3) / 4), dim3(256), 0, stream, cur, count, depth, P.depthCap, leafMax, segLo,
-                       segHi, N2, keys2, splitPos, innerCnt, subCnt, subMax);
-    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, innerCnt, innerOff, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream));
-    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subCnt, subOff, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream));
-    const uint32_t nextBase = levelBase + count;
-    hipLaunchKernelGGL(k_level_emit, dim3((count + 255) / 256), blk, 0, stream, cur, count, levelBase, nextBase, splitPos, innerOff,
-                       leafMax, segLo, segHi, N2, P.pad, P.boxScale, nodes16, nodesF, nxt, subOff, nSub, subs, subMax, depth);
-    uint32_t lastOff = 0, lastCnt = 0, lastSubOff = 0, lastSubCnt = 0;
-    GB_TRY(hipMemcpyAsync(&lastOff, innerOff + (count - 1), 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipMemcpyAsync(&lastCnt, innerCnt + (count - 1), 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipMemcpyAsync(&lastSubOff, subOff + (count - 1), 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipMemcpyAsync(&lastSubCnt, subCnt + (count - 1), 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipStreamSynchronize(stream));
-    maxDepth = depth + 1;  // leaves hang one level below the deepest inner level
-    levelBase = nextBase;
-    count = lastOff + lastCnt;
-    nSub += lastSubOff + lastSubCnt;
-    ++depth;
-    WorkItem* t = cur;
-    cur = nxt, nxt = t;
-  }
-  uint32_t nTotal = levelBase;
-  if (nSub) {
-    // the exact subtrees: scratch blocks of (triangles - 1) node slots each, built one workgroup per range ...
-    hipLaunchKernelGGL(k_sub_sizes, dim3((nSub + 255) / 256), blk, 0, stream, subs, nSub, subSizes);
-    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subSizes, scratchOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
-    // (dynamic LDS beyond 64 KiB is granted per kernel AND per device — one process may build on several devices:
-    // rt_group —, so the grant is tracked per device, as rt_kernels.hip allow_big_lds does)
-    const size_t ldsBytes = subtree_lds_bytes((int)kSubMax);
-    {
-      static std::atomic<unsigned long long> ldsSet{0};
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = -1;
-      if (dev < 0 || !(ldsSet.load() & (1ull << dev))) {
-        GB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_subtree<(int)kSubMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)ldsBytes));
-        if (dev >= 0) ldsSet.fetch_or(1ull << dev);
-      }
-    }
-    hipLaunchKernelGGL((k_subtree<(int)kSubMax>), dim3(nSub), dim3(kSubMax), ldsBytes, stream, subs, scratchOff, order, lo, hi, leafMax,
-                       P.depthCap, scratch, subNodes, height);
-    // ... then numbered behind the top in item order (deterministic) and packed
-    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subNodes, finalOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
-    hipLaunchKernelGGL(k_sub_relocate, dim3(nSub), blk, 0, stream, subs, scratchOff, subNodes, finalOff, levelBase, scratch, P.pad,
-                       P.boxScale, nodes16, nodesF);
-    uint32_t lastOff = 0, lastCnt = 0, h = 0;
-    GB_TRY(hipMemcpyAsync(&lastOff, finalOff + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipMemcpyAsync(&lastCnt, subNodes + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipMemcpyAsync(&h, height, 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipStreamSynchronize(stream));
-    nTotal = levelBase + lastOff + lastCnt;
-    maxDepth = maxDepth > h ? maxDepth : h;
-    if (nTotal > maxNodes) {
-      cleanup();
-      return hipErrorInvalidValue;
-    }
-  }
-  // rotation passes over the whole tree (as the host builder's: 3 on big scenes, 8 on small ones)
-  GB_TRY(rotate_and_pack(nodesF, nodes16, nTotal, P.depthCap, P.boxScale, n > 200000u ? 3 : 8, &maxDepth, stream));
-  // triangle records in the FINAL leaf order (the exact builder has reordered its ranges), and in reference order
-  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
-  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
-  GB_TRY(hipStreamSynchronize(stream));
-  GB_TRY(hipGetLastError());
-  keepOutputs = true;
-  out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;
-  out->n_nodes = nTotal, out->maxDepth = maxDepth;
-  cleanup();
-  return hipSuccess;
-}
 
 // The HYBRID build (rt_options.bvh_builder = RT_BVH_HYBRID): the host builder's own top (rtbvh::buildTop: its split
 // choices down to parts of <= kSubMax triangles) and, below it, the exact subtrees of step 6 — one workgroup per part.
@@ -1042,42 +1258,28 @@ hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, ui
   if (n == 0 || nTop == 0 || top.order.size() != n) return hipErrorInvalidValue;
   for (const rtbvh::TopBuilt::Part& p : top.parts)
     if (p.e <= p.b || p.e - p.b > kSubMax || p.e > n || p.parent >= nTop || p.slot > 1u) return hipErrorInvalidValue;
-  float4 *lo = nullptr, *hi = nullptr, *nodesF = nullptr, *tris = nullptr, *trisRef = nullptr, *scratch = nullptr;
+  const uint32_t maxNodes = n + nTop;
+  const size_t nS = nSub ? nSub : 1u;
+  Arena A;
+  const size_t oLo = A.reserve((size_t)n * sizeof(float4)), oHi = A.reserve((size_t)n * sizeof(float4)), oOrd = A.reserve((size_t)n * 4),
+               oSubs = A.reserve(nS * sizeof(SubItem));
+  float4 *nodesF = nullptr, *tris = nullptr, *trisRef = nullptr;
   uint4* nodes16 = nullptr;
-  int* cb = nullptr;
-  uint32_t *order = nullptr, *subSizes = nullptr, *scratchOff = nullptr, *subNodes = nullptr, *finalOff = nullptr, *height = nullptr;
-  SubItem* subs = nullptr;
-  void* tmp = nullptr;
   bool keepOutputs = false;
   auto cleanup = [&]() {
-    for (void* p : {(void*)lo, (void*)hi, (void*)cb, (void*)order, (void*)subSizes, (void*)scratchOff, (void*)subNodes, (void*)finalOff,
-                    (void*)height, (void*)scratch, (void*)subs, tmp})
-      if (p) (void)hipFree(p);
+    A.release();
     if (!keepOutputs)
       for (void* p : {(void*)nodes16, (void*)nodesF, (void*)tris, (void*)trisRef})
         if (p) (void)hipFree(p);
   };
-  const uint32_t maxNodes = n + nTop;
-  const size_t nS = nSub ? nSub : 1u;
-  GB_TRY(hipMalloc((void**)&lo, (size_t)n * sizeof(float4)));
-  GB_TRY(hipMalloc((void**)&hi, (size_t)n * sizeof(float4)));
-  GB_TRY(hipMalloc((void**)&cb, 6 * sizeof(int)));
-  GB_TRY(hipMalloc((void**)&order, (size_t)n * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&subs, nS * sizeof(SubItem)));
-  GB_TRY(hipMalloc((void**)&subSizes, nS * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&scratchOff, nS * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&subNodes, nS * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&finalOff, nS * sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&height, sizeof(uint32_t)));
-  GB_TRY(hipMalloc((void**)&scratch, 4 * (size_t)n * sizeof(float4)));
+  GB_TRY(A.commit());
   GB_TRY(hipMalloc((void**)&nodes16, 2 * (size_t)maxNodes * sizeof(uint4)));
   GB_TRY(hipMalloc((void**)&nodesF, 4 * (size_t)maxNodes * sizeof(float4)));
   GB_TRY(hipMalloc((void**)&tris, 3 * (size_t)n * sizeof(float4)));
   GB_TRY(hipMalloc((void**)&trisRef, 3 * (size_t)n * sizeof(float4)));
-  size_t scanBytes = 0;
-  GB_TRY(rocprim::exclusive_scan(nullptr, scanBytes, subSizes, scratchOff, 0u, nS, rocprim::plus<uint32_t>(), stream));
-  GB_TRY(hipMalloc(&tmp, scanBytes ? scanBytes : 16));
-  GB_TRY(hipMemsetAsync(height, 0, sizeof(uint32_t), stream));
+  float4 *lo = A.at<float4>(oLo), *hi = A.at<float4>(oHi);
+  uint32_t* order = A.at<uint32_t>(oOrd);
+  SubItem* subs = A.at<SubItem>(oSubs);
   GB_TRY(hipMemcpyAsync(order, top.order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   // the top's records, float and packed (the packing of rtbvh::packNodes; part refs are patched in by k_sub_relocate)
   std::vector<rtbvh::Node16> top16(nTop);
@@ -1101,46 +1303,173 @@ hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, ui
   std::vector<SubItem> hs(nSub);
   for (uint32_t i = 0; i < nSub; ++i) hs[i] = SubItem{top.parts[i].b, top.parts[i].e, top.parts[i].depth, top.parts[i].parent, top.parts[i].slot};
   if (nSub) GB_TRY(hipMemcpyAsync(subs, hs.data(), (size_t)nSub * sizeof(SubItem), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_tri_boxes, dim3((n + 255) / 256), dim3(256), 0, stream, dVpos, dTriShade, n, lo, hi);
+  GB_TRY(hipStreamSynchronize(stream));  // (the host vectors above go out of scope)
+  uint32_t nTotal = 0, maxDepth = 0;
+  GB_TRY(subtrees_and_finish(dVpos, dTriShade, n, nTop, nSub, subs, order, lo, hi, top.leafMax, top.depthCap, top.pad, top.boxScale, top.maxDepth,
+                             maxNodes, nodesF, nodes16, tris, trisRef, &nTotal, &maxDepth, stream));
+  keepOutputs = true;
+  out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;
+  out->n_nodes = nTotal, out->maxDepth = maxDepth;
+  cleanup();
+  return hipSuccess;
+}
+
+// The EXACT device build (rt_options.bvh_builder = RT_BVH_DEVICE, and what RT_BVH_AUTO takes for big scenes): the host
+// builder's split rules as kernels for the ranges above kSubMax triangles (k_top_*), then the exact subtrees, the rotation
+// passes and the numbering every device build ends with.  `hSizeKey`: the host's size keys (rtbvh::planSceneExact).
+// *needHost = true (and nothing built): a range needs the host's median split — the caller takes the hybrid path.
+hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const float* hSizeKey, uint32_t n, const rtbvh::ScenePlan& P,
+                               GpuBvh* out, bool* needHost, hipStream_t stream) {
+  *out = GpuBvh{};
+  *needHost = false;
+  if (n == 0 || !hSizeKey) return hipErrorInvalidValue;
+  const uint32_t leafMax = P.leafMax;
+  const uint32_t maxItems = n / kSubMax + 2u;              // ranges of one level: disjoint, more than kSubMax triangles each
+  const uint32_t maxBlk = n / kTopChunk + maxItems + 1u;   // their workgroups
+  const uint32_t maxBinned = n / kSweepMaxD + 2u;
+  const uint32_t maxSub = n / (leafMax + 1u) + 2u;         // parts hold more than leafMax triangles
+  const uint32_t maxNodes = n;                             // a binary tree over n triangles, at least one per leaf
+  Arena A;
+  const size_t oLo = A.reserve((size_t)n * sizeof(float4)), oHi = A.reserve((size_t)n * sizeof(float4)), oKey = A.reserve((size_t)n * 4),
+               oOrd = A.reserve((size_t)n * 4), oTmp = A.reserve((size_t)n * 4), oItems = A.reserve((size_t)maxItems * sizeof(TopItem)),
+               oBlkItem = A.reserve((size_t)maxBlk * 4), oSweep = A.reserve((size_t)maxItems * 4), oIb = A.reserve((size_t)maxItems * 32),
+               oPrep = A.reserve((size_t)maxItems * sizeof(TopPrep)), oDec = A.reserve((size_t)maxItems * sizeof(TopDec)),
+               oMid = A.reserve((size_t)maxItems * 4), oRefs = A.reserve((size_t)maxItems * 8), oCbx = A.reserve((size_t)maxItems * 48),
+               oBlockLeft = A.reserve((size_t)maxBlk * 4), oBins = A.reserve((size_t)maxBinned * 4u * 64u * 7u * 4u),
+               oFlag = A.reserve(8), oSubs = A.reserve((size_t)maxSub * sizeof(SubItem));
+  float4 *nodesF = nullptr, *tris = nullptr, *trisRef = nullptr;
+  uint4* nodes16 = nullptr;
+  bool keepOutputs = false;
+  auto cleanup = [&]() {
+    A.release();
+    if (!keepOutputs)
+      for (void* p : {(void*)nodes16, (void*)nodesF, (void*)tris, (void*)trisRef})
+        if (p) (void)hipFree(p);
+  };
+  GB_TRY(A.commit());
+  GB_TRY(hipMalloc((void**)&nodes16, 2 * (size_t)maxNodes * sizeof(uint4)));
+  GB_TRY(hipMalloc((void**)&nodesF, 4 * (size_t)maxNodes * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&tris, 3 * (size_t)n * sizeof(float4)));
+  GB_TRY(hipMalloc((void**)&trisRef, 3 * (size_t)n * sizeof(float4)));
+  float4 *lo = A.at<float4>(oLo), *hi = A.at<float4>(oHi);
+  float* skey = A.at<float>(oKey);
+  uint32_t *ord = A.at<uint32_t>(oOrd), *tmp = A.at<uint32_t>(oTmp), *blkItem = A.at<uint32_t>(oBlkItem), *sweepList = A.at<uint32_t>(oSweep),
+           *mid = A.at<uint32_t>(oMid), *blockLeft = A.at<uint32_t>(oBlockLeft), *flag = A.at<uint32_t>(oFlag);
+  TopItem* items = A.at<TopItem>(oItems);
+  int *ib = A.at<int>(oIb), *cbx = A.at<int>(oCbx), *bins = A.at<int>(oBins);
+  TopPrep* prep = A.at<TopPrep>(oPrep);
+  TopDec* dec = A.at<TopDec>(oDec);
+  int32_t* refs = A.at<int32_t>(oRefs);
+  SubItem* subs = A.at<SubItem>(oSubs);
+  RNode* nodes = reinterpret_cast<RNode*>(nodesF);
+
   const dim3 blk(256), grdN((n + 255) / 256);
-  hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, cb);
-  hipLaunchKernelGGL(k_tri_boxes, grdN, blk, 0, stream, dVpos, dTriShade, n, lo, hi, cb);
-  uint32_t nTotal = nTop, maxDepth = top.maxDepth;
-  if (nSub) {
-    hipLaunchKernelGGL(k_sub_sizes, dim3((nSub + 255) / 256), blk, 0, stream, subs, nSub, subSizes);
-    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subSizes, scratchOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
-    const size_t ldsBytes = subtree_lds_bytes((int)kSubMax);
-    {
-      static std::atomic<unsigned long long> ldsSet{0};
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = -1;
-      if (dev < 0 || !(ldsSet.load() & (1ull << dev))) {
-        GB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_subtree<(int)kSubMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)ldsBytes));
-        if (dev >= 0) ldsSet.fetch_or(1ull << dev);
-      }
+  GB_TRY(hipMemcpyAsync(skey, hSizeKey, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+  GB_TRY(hipMemsetAsync(flag, 0, 8, stream));
+  hipLaunchKernelGGL(k_tri_boxes, grdN, blk, 0, stream, dVpos, dTriShade, n, lo, hi);
+  hipLaunchKernelGGL(k_iota, grdN, blk, 0, stream, ord, n);
+  static std::atomic<unsigned long long> sweepLds{0};
+  GB_TRY(grant_lds(reinterpret_cast<const void*>(&k_top_sweep), kSweepLds, sweepLds));
+
+  struct HItem {
+    uint32_t b, e, node;
+  };
+  std::vector<HItem> cur{{0u, n, 0u}}, next;
+  std::vector<TopItem> hItems;
+  std::vector<uint32_t> hBlk, hSweep, hMid;
+  std::vector<int32_t> hRefs;
+  uint32_t nTop = 1, nSub = 0, depth = 0, topMaxDepth = 0;
+  if (n <= kSubMax) {  // the whole scene is one exact subtree: no top
+    const SubItem whole{0u, n, 0u, ~0u, 0u};
+    GB_TRY(hipMemcpy(subs, &whole, sizeof whole, hipMemcpyHostToDevice));
+    cur.clear(), nTop = 0, nSub = 1;
+  }
+  while (!cur.empty()) {
+    const uint32_t count = (uint32_t)cur.size();
+    if ((int)depth >= rtbvh::kMaxDepth - 1 || count > maxItems) {
+      cleanup();
+      return hipErrorInvalidValue;  // (cannot happen: the split choice enforces the depth budget)
     }
-    hipLaunchKernelGGL((k_subtree<(int)kSubMax>), dim3(nSub), dim3(kSubMax), ldsBytes, stream, subs, scratchOff, order, lo, hi, top.leafMax,
-                       top.depthCap, scratch, subNodes, height);
-    GB_TRY(rocprim::exclusive_scan(tmp, scanBytes, subNodes, finalOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
-    hipLaunchKernelGGL(k_sub_relocate, dim3(nSub), blk, 0, stream, subs, scratchOff, subNodes, finalOff, nTop, scratch, top.pad,
-                       top.boxScale, nodes16, nodesF);
-    uint32_t lastOff = 0, lastCnt = 0, h = 0;
-    GB_TRY(hipMemcpyAsync(&lastOff, finalOff + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipMemcpyAsync(&lastCnt, subNodes + (nSub - 1), 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipMemcpyAsync(&h, height, 4, hipMemcpyDeviceToHost, stream));
-    GB_TRY(hipStreamSynchronize(stream));
-    nTotal = nTop + lastOff + lastCnt;
-    maxDepth = maxDepth > h ? maxDepth : h;
-    if (nTotal > maxNodes) {
+    hItems.resize(count), hBlk.clear(), hSweep.clear();
+    uint32_t nBinned = 0;
+    for (uint32_t r = 0; r < count; ++r) {
+      const uint32_t sz = cur[r].e - cur[r].b;
+      TopItem& it = hItems[r];
+      it.b = cur[r].b, it.e = cur[r].e, it.blk0 = (uint32_t)hBlk.size(), it.node = cur[r].node, it.pad0 = it.pad1 = 0;
+      it.nb = sz > kSweepMaxD ? (sz >= 65536u ? 64u : 16u) : 0u;
+      it.binIdx = it.nb ? nBinned++ : (uint32_t)hSweep.size();
+      if (!it.nb) hSweep.push_back(r);
+      hBlk.insert(hBlk.end(), (sz + kTopChunk - 1u) / kTopChunk, r);
+    }
+    const uint32_t nBlk = (uint32_t)hBlk.size(), nSweep = (uint32_t)hSweep.size();
+    if (nBlk > maxBlk || nBinned > maxBinned) {
       cleanup();
       return hipErrorInvalidValue;
     }
+    GB_TRY(hipMemcpy(items, hItems.data(), (size_t)count * sizeof(TopItem), hipMemcpyHostToDevice));
+    GB_TRY(hipMemcpy(blkItem, hBlk.data(), (size_t)nBlk * 4, hipMemcpyHostToDevice));
+    if (nSweep) GB_TRY(hipMemcpy(sweepList, hSweep.data(), (size_t)nSweep * 4, hipMemcpyHostToDevice));
+    const dim3 grdI((count + 255) / 256);
+    hipLaunchKernelGGL(k_top_init, dim3((count * 12u + 255u) / 256u), blk, 0, stream, count, ib, cbx);
+    hipLaunchKernelGGL(k_top_bounds, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, skey, ib);
+    hipLaunchKernelGGL(k_top_prep, grdI, blk, 0, stream, items, count, ib, prep, bins);
+    if (nBinned) {
+      hipLaunchKernelGGL(k_top_bins, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, skey, prep, bins);
+      hipLaunchKernelGGL(k_top_choose, grdI, blk, 0, stream, items, count, depth, P.depthCap, leafMax, prep, bins, dec, mid, flag);
+      hipLaunchKernelGGL(k_top_count, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, skey, dec, blockLeft);
+      hipLaunchKernelGGL(k_top_offsets, dim3(count), dim3(64), 0, stream, items, blockLeft);
+      hipLaunchKernelGGL(k_top_scatter, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, skey, dec, mid, blockLeft, tmp);
+      hipLaunchKernelGGL(k_top_copyback, dim3(nBlk), blk, 0, stream, items, blkItem, tmp, ord);
+    }
+    if (nSweep)
+      hipLaunchKernelGGL(k_top_sweep, dim3(nSweep), dim3(kSweepT), kSweepLds, stream, items, sweepList, depth, P.depthCap, leafMax, ib, lo, hi,
+                         skey, ord, tmp, mid, flag);
+    hMid.resize(count);
+    uint32_t hostFlag = 0;
+    GB_TRY(hipMemcpyAsync(hMid.data(), mid, (size_t)count * 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipMemcpyAsync(&hostFlag, flag, 4, hipMemcpyDeviceToHost, stream));
+    GB_TRY(hipStreamSynchronize(stream));
+    GB_TRY(hipGetLastError());
+    if (hostFlag) {
+      cleanup();
+      *needHost = true;
+      return hipSuccess;
+    }
+    // the children: leaves (<= leafMax), parts (<= kSubMax: one exact subtree each), or ranges of the next level
+    next.clear(), hRefs.resize(2 * (size_t)count);
+    for (uint32_t r = 0; r < count; ++r) {
+      const uint32_t m = hMid[r];
+      if (m <= cur[r].b || m >= cur[r].e) {
+        cleanup();
+        return hipErrorInvalidValue;
+      }
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t cb0 = c ? m : cur[r].b, ce0 = c ? cur[r].e : m, sz = ce0 - cb0;
+        int32_t ref;
+        if (sz <= leafMax) ref = rtbvh::encodeLeaf(cb0, sz), topMaxDepth = depth + 1u;
+        else if (sz <= kSubMax) ref = (int32_t)~(rtbvh::kPartFlag | nSub++), topMaxDepth = depth + 1u;
+        else ref = (int32_t)nTop, next.push_back(HItem{cb0, ce0, nTop++});
+        hRefs[2 * (size_t)r + c] = ref;
+      }
+    }
+    if (nSub > maxSub || nTop > maxNodes) {
+      cleanup();
+      return hipErrorInvalidValue;
+    }
+    GB_TRY(hipMemcpy(refs, hRefs.data(), 2 * (size_t)count * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_top_childbox, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, mid, cbx);
+    hipLaunchKernelGGL(k_top_emit, grdI, blk, 0, stream, items, count, depth, mid, refs, cbx, P.pad, ord, nodes, subs);
+    // (the next level's uploads overwrite `items` and `refs`: the kernels above must have read them)
+    GB_TRY(hipStreamSynchronize(stream));
+    cur.swap(next);
+    ++depth;
   }
-  GB_TRY(rotate_and_pack(nodesF, nodes16, nTotal, top.depthCap, top.boxScale, n > 200000u ? 3 : 8, &maxDepth, stream));
-  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, order, n, tris);
-  hipLaunchKernelGGL(k_tri_records, grdN, blk, 0, stream, dVpos, dTriShade, (const uint32_t*)nullptr, n, trisRef);
-  GB_TRY(hipStreamSynchronize(stream));
-  GB_TRY(hipGetLastError());
+  // the top's packed records (the smaller box is in slot 0 already: k_rot_pack changes no slot the parts were registered with)
+  if (nTop) hipLaunchKernelGGL(k_rot_pack, dim3((nTop + 255) / 256), blk, 0, stream, nodes, nTop, P.boxScale, nodes16);
+  uint32_t nTotal = 0, maxDepth = 0;
+  GB_TRY(subtrees_and_finish(dVpos, dTriShade, n, nTop, nSub, subs, ord, lo, hi, leafMax, P.depthCap, P.pad, P.boxScale, topMaxDepth, maxNodes,
+                             nodesF, nodes16, tris, trisRef, &nTotal, &maxDepth, stream));
   keepOutputs = true;
   out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;
   out->n_nodes = nTotal, out->maxDepth = maxDepth;

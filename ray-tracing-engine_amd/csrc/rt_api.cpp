@@ -434,15 +434,16 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     delete c;
     return fail(RT_ERR_INVALID, "unknown bvh_builder %u", wantBuilder);
   }
-  // AUTO: the hybrid builder gives the host builder's tree (same node visits, same frame time: profiles/r04_builders.txt)
-  // 2-3 x sooner, so big scenes take it; trees that fit the LDS-resident top keep the host builder, whose node ORDER (most
+  // AUTO: the device builder gives the host builder's tree (same node visits, same frame time: profiles/r04_builders.txt)
+  // 8 x sooner, so big scenes take it; trees that fit the LDS-resident top keep the host builder, whose node ORDER (most
   // visited first) that top is cut from, and a group of contexts shares one host-built tree
-  if (wantBuilder == RT_BVH_AUTO) wantBuilder = (sc->n_triangles >= 131072u && !prebuilt) ? (uint32_t)RT_BVH_HYBRID : (uint32_t)RT_BVH_HOST;
+  if (wantBuilder == RT_BVH_AUTO) wantBuilder = (sc->n_triangles >= 131072u && !prebuilt) ? (uint32_t)RT_BVH_DEVICE : (uint32_t)RT_BVH_HOST;
   // (a scene of a single part has no top to build on the host: the device builder's own path handles it)
   const bool hybrid = wantBuilder == RT_BVH_HYBRID && sc->n_triangles > 1024u;
   const bool gpuBuild = (wantBuilder == RT_BVH_DEVICE || wantBuilder == RT_BVH_HYBRID) && sc->n_triangles >= 16;
   rtbvh::TopBuilt topBuilt;
   rtbvh::ScenePlan plan;
+  std::vector<float> sizeKey;
   const auto tBuild0 = std::chrono::steady_clock::now();
   try {
     if (hybrid) {
@@ -453,8 +454,10 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
       c->bvh.leafMax = topBuilt.leafMax, c->bvh.pad = topBuilt.pad, c->bvh.originBound = topBuilt.originBound, c->bvh.boxScale = topBuilt.boxScale;
       c->bvh.depthCap = topBuilt.depthCap;
     } else if (gpuBuild) {
-      plan = rtbvh::planScene(*sc, opt ? opt->bvh_leaf_max : 0);
+      // (the device build restates the host builder's splits: it takes the host's depth cap and size keys)
+      plan = rtbvh::planSceneExact(*sc, opt ? opt->bvh_leaf_max : 0, sizeKey);
       c->bvh.leafMax = plan.leafMax, c->bvh.pad = plan.pad, c->bvh.originBound = plan.originBound, c->bvh.boxScale = plan.boxScale;
+      c->bvh.depthCap = plan.depthCap;
     } else if (prebuilt) {
       c->bvh = *prebuilt;
     } else {
@@ -482,8 +485,27 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   UP(vnrm, sc->vertex_nrm, (size_t)sc->n_vertices * 3);
   if (gpuBuild) {
     rtk::GpuBvh G;
-    hipError_t he = hybrid ? rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sc->n_triangles, topBuilt, &G, nullptr)
-                           : rtk::gpu_bvh_build(S.vpos, S.triShade, sc->n_triangles, plan, &G, nullptr);
+    hipError_t he = hipSuccess;
+    bool fellBack = false;
+    if (hybrid) {
+      he = rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sc->n_triangles, topBuilt, &G, nullptr);
+    } else {
+      bool needHost = false;
+      he = rtk::gpu_bvh_build_exact(S.vpos, S.triShade, sizeKey.data(), sc->n_triangles, plan, &G, &needHost, nullptr);
+      if (he == hipSuccess && needHost) {
+        // a range the host builder would cut at its median (coincident centroids, a spent depth budget): the host's top it is
+        try {
+          rtbvh::buildTop(*sc, opt ? opt->bvh_leaf_max : 0, 1024u, topBuilt);
+        } catch (const std::exception& e) {
+          rt_destroy(c);
+          return fail(RT_ERR_INVALID, "scene rejected: %s", e.what());
+        }
+        c->bvh.depthCap = topBuilt.depthCap;
+        he = rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sc->n_triangles, topBuilt, &G, nullptr);
+        fellBack = true;
+        if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "exact device build: a range needs the host's median split; hybrid build instead\n");
+      }
+    }
     if (he != hipSuccess) {
       rt_destroy(c);
       return fail(RT_ERR_HIP, "device BVH build failed: %s", hipGetErrorString(he));
@@ -493,7 +515,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     c->dNodesF = G.nodesF;
     c->bvh.maxDepth = G.maxDepth;
     S.n_nodes = G.n_nodes;
-    c->builder = hybrid ? RT_BVH_HYBRID : RT_BVH_DEVICE;
+    c->builder = (hybrid || fellBack) ? RT_BVH_HYBRID : RT_BVH_DEVICE;
   } else {
     UP(nodes, c->bvh.nodes16.data(), c->bvh.nodes16.size() * 2);
     UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);

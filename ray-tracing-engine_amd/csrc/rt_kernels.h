@@ -116,12 +116,14 @@ hipError_t launch_emit(const DevScene& S, uint32_t perLight, uint32_t seed, floa
 struct GpuBvh {
   uint4* nodes16 = nullptr;   // n_nodes x 32 B (what the kernels traverse)
   float4* nodesF = nullptr;   // n_nodes x 64 B (rtbvh::Node: inspection / export)
-  float4* tris = nullptr;     // leaf (Morton) order
+  float4* tris = nullptr;     // leaf order
   float4* trisRef = nullptr;  // reference order
   uint32_t n_nodes = 0, maxDepth = 0;
 };
-hipError_t gpu_bvh_build(const float* dVpos, const uint4* dTriShade, uint32_t n_tris, const rtbvh::ScenePlan& plan, GpuBvh* out,
-                         hipStream_t stream);
+// the exact build: the host builder's split rules as kernels above the exact subtrees (hSizeKey: rtbvh::planSceneExact);
+// *needHost: a range needs the host's median split, nothing was built — take the hybrid build
+hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const float* hSizeKey, uint32_t n_tris, const rtbvh::ScenePlan& plan,
+                               GpuBvh* out, bool* needHost, hipStream_t stream);
 // the hybrid build: the host builder's top (rtbvh::buildTop), exact subtrees of its parts on the device
 hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, uint32_t n_tris, const rtbvh::TopBuilt& top, GpuBvh* out,
                                   hipStream_t stream);

@@ -1,8 +1,8 @@
-"""The BVH built on the device (csrc/bvh_gpu.hip, rt_options.bvh_builder = RT_BVH_DEVICE):
-same arrays, same exactness bar as the host SAH builder — BVH == exhaustive loop ==
-oracle on all four scenes — plus the structural invariants, the depth cap, determinism,
-build time and traversal cost next to the host tree.  (The whole GPU suite also runs on
-device-built trees with RT_BVH_GPU=1.)"""
+"""The BVH built on the device (csrc/bvh_gpu.hip, rt_options.bvh_builder = RT_BVH_DEVICE — what RT_BVH_AUTO takes from
+131,072 triangles): the host builder's split rules as kernels.  Same arrays, same exactness bar as the host SAH builder —
+BVH == exhaustive loop == oracle on all four scenes — plus the structural invariants, the depth cap, determinism, and the
+claim itself: the HOST builder's tree (node count, depth, node visits and triangle tests per ray), in a fraction of its
+time.  (The whole GPU suite also runs on device-built trees with RT_BVH_GPU=1.)"""
 import os
 
 import numpy as np
@@ -95,9 +95,9 @@ def test_frames_on_device_built_tree_vs_oracle(kind, w, h, spp):
 
 
 def test_device_builder_variants_are_exact(tmp_path):
-    """The builders' other configurations (environment knobs, read once per process): Morton cuts all the
-    way down (RT_BVH_GPU_SUB=0, round 2's tree), exact subtrees of <= 64 triangles, the host builder's variants and the
-    hybrid builder.  Every one must give the exhaustive loop's hits and the default tree's frame."""
+    """The builders' other configurations (environment knobs, read once per process): the host builder's variants, the
+    hybrid builder, the device builder without its rotation passes / final numbering.  Every one must give the exhaustive
+    loop's hits and the default tree's frame."""
     import subprocess
     import sys
     script = tmp_path / "v.py"
@@ -120,7 +120,7 @@ for kind, w, spp, n in (("lowres", 64, 4, 60000), ("hires", 48, 3, 60000), ("str
 np.savez(sys.argv[2], **out)
 ''')
     runs = {}
-    for name, env in (("default", {}), ("morton_all_the_way", {"RT_BVH_GPU_SUB": "0"}), ("subtrees_64", {"RT_BVH_GPU_SUB": "64"}),
+    for name, env in (("default", {}), ("no_rotations", {"RT_BVH_GPU_ROT": "0"}), ("breadth_first_numbering", {"RT_BVH_GPU_PREORDER": "0"}),
                       # ... and the host builder's: its default, without the size axis, with an unbiased size axis,
                       # without the rotation passes
                       ("host", {"RT_TEST_HOST_BUILDER": "1"}), ("host_no_size_axis", {"RT_TEST_HOST_BUILDER": "1", "RT_BVH_SIZEAXIS": "0"}),
@@ -141,11 +141,10 @@ np.savez(sys.argv[2], **out)
 
 
 def test_build_time_and_tree_quality_report(capsys):
-    """The device build of the 1M-triangle scene must beat the host build's time, and — since the exact
-    subtree builder of round 3 (bvh_gpu.hip k_subtree) — its traversal cost (nodes per ray of a
-    256x256x4 frame) must stay within 1.10x of the host SAH tree's (measured: lowres 1.04x, hires 1.09x,
-    stress 1.07x against the host tree WITH its size axis, bvh_build.cpp split(); against the round-2 host
-    tree 0.94x / 0.92x / 1.07x; Morton cuts all the way down, RT_BVH_GPU_SUB=0, were 1.29x / 1.17x / 1.19x)."""
+    """The device builder restates the host builder's splits, so it must produce the host builder's TREE: the same node count
+    and depth and — on a counted 256x256x4 frame — node visits and triangle tests per ray within 0.2 % (measured: identical to
+    the last printed digit on hires and stress, 7.800 against 7.801 on lowres, where the 1,024-triangle subtrees sweep three
+    axes and the host four), and build the 1 M-triangle scene several times sooner (21 ms against 170-180)."""
     rows = []
     for kind, n in (("lowres", 200000), ("hires", 200000), ("stress", 200000)):
         s = pyrt.Scene(kind, 256, 256)
@@ -167,10 +166,9 @@ def test_build_time_and_tree_quality_report(capsys):
                   % ((kind,) + out["host"] + out["device"] + out["hybrid"]), end="")
         print()
     for kind, out in rows:
-        assert out["device"][3] < 1.10 * out["host"][3], (kind, out)
-        # the hybrid tree has the host's own top: what is left is the host's rotation passes and the size axis of its sweeps
-        # (measured: lowres 1.000x, hires 1.001x, stress 1.037x)
-        assert out["hybrid"][3] < 1.05 * out["host"][3], (kind, out)
+        for name in ("device", "hybrid"):
+            assert abs(out[name][3] / out["host"][3] - 1) < 0.002 and abs(out[name][4] / out["host"][4] - 1) < 0.002, (kind, name, out)
+            assert abs(out[name][1] - out["host"][1]) <= 4 and out[name][2] == out["host"][2], (kind, name, out)
     stress = dict(rows)["stress"]
-    if not os.environ.get("RT_BVH_GPU"):  # (the variable forces the device builder for "host" too)
-        assert stress["device"][0] < stress["hybrid"][0] < stress["host"][0]
+    if not os.environ.get("RT_BVH_GPU"):  # (the variable forces one builder for all three)
+        assert 3 * stress["device"][0] < stress["host"][0] and stress["device"][0] < stress["hybrid"][0] < stress["host"][0]
