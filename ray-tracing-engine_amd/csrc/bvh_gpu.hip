@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 
 #include <cstdio>
 #include <cstring>  // (rocPRIM's headers use memset without including it)
@@ -1365,6 +1366,9 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
   RNode* nodes = reinterpret_cast<RNode*>(nodesF);
 
   const dim3 blk(256), grdN((n + 255) / 256);
+  const bool verbose = getenv("RT_BVH_VERBOSE") != nullptr;
+  const auto tB0 = std::chrono::steady_clock::now();
+  auto msSince = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tB0).count(); };
   GB_TRY(hipMemcpyAsync(skey, hSizeKey, (size_t)n * 4, hipMemcpyHostToDevice, stream));
   GB_TRY(hipMemsetAsync(flag, 0, 8, stream));
   hipLaunchKernelGGL(k_tri_boxes, grdN, blk, 0, stream, dVpos, dTriShade, n, lo, hi);
@@ -1467,13 +1471,18 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
   }
   // the top's packed records (the smaller box is in slot 0 already: k_rot_pack changes no slot the parts were registered with)
   if (nTop) hipLaunchKernelGGL(k_rot_pack, dim3((nTop + 255) / 256), blk, 0, stream, nodes, nTop, P.boxScale, nodes16);
+  const double tTop = msSince();
   uint32_t nTotal = 0, maxDepth = 0;
   GB_TRY(subtrees_and_finish(dVpos, dTriShade, n, nTop, nSub, subs, ord, lo, hi, leafMax, P.depthCap, P.pad, P.boxScale, topMaxDepth, maxNodes,
                              nodesF, nodes16, tris, trisRef, &nTotal, &maxDepth, stream));
   keepOutputs = true;
   out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;
   out->n_nodes = nTotal, out->maxDepth = maxDepth;
+  const double tDone = msSince();
   cleanup();
+  if (verbose)
+    fprintf(stderr, "device build: top of %u nodes over %u parts in %u levels %.2f ms (allocations included), subtrees + rotations + records %.2f ms, release %.2f ms\n",
+            nTop, nSub, depth, tTop, tDone - tTop, msSince() - tDone);
   return hipSuccess;
 }
 

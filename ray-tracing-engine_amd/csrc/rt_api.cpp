@@ -7,15 +7,18 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -410,6 +413,23 @@ int rt_create(const rt_scene_desc* sc, const rt_options* opt, rt_ctx** out) { re
 }  // extern "C"
 
 namespace {
+// f(thread, begin, end) over contiguous chunks of [b, e): up to 16 threads, one per 2^18 elements
+template <class F>
+void par_chunks(size_t b, size_t e, F f) {
+  static const uint32_t hw = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  const size_t n = e > b ? e - b : 0;
+  const uint32_t T = (uint32_t)std::max<size_t>(1, std::min<size_t>(hw, n >> 18));
+  if (T <= 1u) {
+    f(0u, b, e);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(T - 1u);
+  for (uint32_t t = 1; t < T; ++t) th.emplace_back([&f, b, n, t, T] { f(t, b + n * t / T, b + n * (t + 1) / T); });
+  f(0u, b, b + n / T);
+  for (std::thread& x : th) x.join();
+}
+
 int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Built* prebuilt, rt_ctx** out) {
   if (!sc || !out) return fail(RT_ERR_INVALID, "scene/out is null");
   *out = nullptr;
@@ -456,6 +476,8 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     } else if (gpuBuild) {
       // (the device build restates the host builder's splits: it takes the host's depth cap and size keys)
       plan = rtbvh::planSceneExact(*sc, opt ? opt->bvh_leaf_max : 0, sizeKey);
+      if (getenv("RT_BVH_VERBOSE"))
+        fprintf(stderr, "device builder: validation + size keys in %.2f ms\n", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count());
       c->bvh.leafMax = plan.leafMax, c->bvh.pad = plan.pad, c->bvh.originBound = plan.originBound, c->bvh.boxScale = plan.boxScale;
       c->bvh.depthCap = plan.depthCap;
     } else if (prebuilt) {
@@ -469,10 +491,13 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   }
   static_assert(sizeof(rtbvh::Node16) == 2 * sizeof(uint4), "node layout");
   static_assert(sizeof(rtbvh::TriRec) == 3 * sizeof(float4), "triangle layout");
-  std::vector<uint4> shade(sc->n_triangles);
+  // (big scenes: the per-triangle and per-vertex host passes of rt_create are shared by a few threads — 8 M triangles
+  // spent 60 ms in them on one)
+  std::unique_ptr<uint4[]> shade(new uint4[sc->n_triangles]);
   for (uint32_t m = 0; m < sc->n_meshes; ++m)
-    for (uint32_t t = sc->mesh_tri_begin[m]; t < sc->mesh_tri_begin[m + 1]; ++t)
-      shade[t] = make_uint4(sc->tri_vtx[3 * (size_t)t], sc->tri_vtx[3 * (size_t)t + 1], sc->tri_vtx[3 * (size_t)t + 2], m);
+    par_chunks(sc->mesh_tri_begin[m], sc->mesh_tri_begin[m + 1], [&](uint32_t, size_t tb, size_t te) {
+      for (size_t t = tb; t < te; ++t) shade[t] = make_uint4(sc->tri_vtx[3 * t], sc->tri_vtx[3 * t + 1], sc->tri_vtx[3 * t + 2], m);
+    });
 
   rtk::DevScene& S = c->S;
 #define UP(field, src, n)                                  \
@@ -480,10 +505,13 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     rt_destroy(c);                                         \
     return rc;                                             \
   }
-  UP(triShade, shade.data(), shade.size());
+  UP(triShade, shade.get(), (size_t)sc->n_triangles);
+  shade.reset();
   UP(vpos, sc->vertex_pos, (size_t)sc->n_vertices * 3);
   UP(vnrm, sc->vertex_nrm, (size_t)sc->n_vertices * 3);
   if (gpuBuild) {
+    if (getenv("RT_BVH_VERBOSE"))
+      fprintf(stderr, "scene arrays on the device %.2f ms after the start\n", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count());
     rtk::GpuBvh G;
     hipError_t he = hipSuccess;
     bool fellBack = false;
@@ -560,6 +588,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     }
   }
   c->buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count();
+  if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "tree resident %.2f ms after the start\n", c->buildMs);
   UP(mats, sc->materials, sc->n_meshes);
   {
     std::vector<rtd::DevMat> dm(sc->n_meshes);
@@ -594,14 +623,28 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
   {
     double maxAbs = 0, maxLight = 0, maxAny = 0;
     bool finite = true;
+    // (a non-finite value has all exponent bits set: its magnitude bits compare above every finite float's)
     auto eat = [&](const float* p, size_t n) {
-      for (size_t i = 0; i < n; ++i) {
-        finite = finite && std::isfinite(p[i]);
-        maxAny = std::max(maxAny, (double)std::fabs(p[i]));
-      }
+      uint32_t top[64] = {0};
+      par_chunks(0, n, [&](uint32_t th, size_t b, size_t e) {
+        uint32_t m = 0;
+        for (size_t i = b; i < e; ++i) {
+          uint32_t u;
+          memcpy(&u, p + i, 4);
+          u &= 0x7fffffffu;
+          m = u > m ? u : m;
+        }
+        top[th] = m;
+      });
+      uint32_t m = 0;
+      for (uint32_t t : top) m = t > m ? t : m;
+      float f;
+      memcpy(&f, &m, 4);
+      if (m >= 0x7f800000u) finite = false;
+      else maxAny = std::max(maxAny, (double)f);
+      return m >= 0x7f800000u ? 0.0 : (double)f;
     };
-    for (size_t i = 0; i < 3 * (size_t)sc->n_vertices; ++i) maxAbs = std::max(maxAbs, (double)std::fabs(sc->vertex_pos[i]));
-    eat(sc->vertex_pos, 3 * (size_t)sc->n_vertices);
+    maxAbs = eat(sc->vertex_pos, 3 * (size_t)sc->n_vertices);
     eat(sc->vertex_nrm, 3 * (size_t)sc->n_vertices);
     eat(sc->camera.position, 12);
     for (uint32_t l = 0; l < sc->n_lights; ++l) {
