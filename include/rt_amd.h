@@ -87,8 +87,8 @@ enum { RT_TRACE_CLOSEST = 0, RT_TRACE_ANY = 1 };
 typedef struct rt_options {
   int32_t device;          /* HIP device ordinal                              */
   uint32_t bvh_leaf_max;   /* 0 = default (2), max 8                          */
-  uint32_t bvh_builder;    /* RT_BVH_*; AUTO = the hybrid builder for scenes of 131,072 triangles and
-                              more (the same tree as the host builder's, 2-3 x sooner), the host
+  uint32_t bvh_builder;    /* RT_BVH_*; AUTO = the device builder for scenes of 131,072 triangles and
+                              more (the same tree as the host builder's, 8-14 x sooner), the host
                               builder below (its node order feeds the LDS-resident tree top).  The
                               environment variable RT_BVH_GPU=1|2|3 forces DEVICE | HYBRID | HOST   */
   uint32_t node_format;    /* RT_NODES_*: the node records the pooled render kernel and rt_trace
@@ -96,10 +96,11 @@ typedef struct rt_options {
   uint32_t reserved[4];
 } rt_options;
 /* RT_BVH_HOST:   SAH on up to 16 host threads (binned above 4,096 triangles, exact sweeps below, size axis, rotations).
- * RT_BVH_DEVICE: Morton-order top, exact SAH subtrees of <= 1,024 triangles (one workgroup each), rotations, on the GPU.
- * RT_BVH_HYBRID: the host builder's own top, stopped at parts of <= 1,024 triangles, each of which becomes one exact
- *                SAH subtree on the device (where the host build spends most of its time), then the host's rotation
- *                passes and pre-order numbering as kernels: the SAME tree as RT_BVH_HOST's on the lattice scenes.      */
+ * RT_BVH_DEVICE: the same split rules as kernels down to parts of <= 1,024 triangles, each part one exact SAH subtree (one
+ *                workgroup), then the host's rotation passes and a pre-order numbering as kernels: the SAME tree as
+ *                RT_BVH_HOST's (node visits per ray equal to the last digit on the four preset scenes), 1 M triangles in
+ *                20 ms.  A range that needs the host's median split (coincident centroids) makes it take RT_BVH_HYBRID.
+ * RT_BVH_HYBRID: the host builder's own top, stopped at the same parts; everything below as RT_BVH_DEVICE.                 */
 enum { RT_BVH_AUTO = 0, RT_BVH_DEVICE = 1, RT_BVH_HYBRID = 2, RT_BVH_HOST = 3 };
 /* RT_NODES_F16: 32-byte records, 12 binary16 box planes + 2 child refs (two 16-byte requests per visit).
  * RT_NODES_Q8:  16-byte records, 12 8-bit box planes in the frame of the record's 16-KiB block + one

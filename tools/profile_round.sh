@@ -31,5 +31,6 @@ echo "pmc done"
 tools/phase_timing.sh C2 C4 C5 > $out/phase.log 2>&1; for w in C2 C4 C5; do [ -s gpurun_out/phase_$w.json ] && cp gpurun_out/phase_$w.json $out/; done
 echo "phase done"
 python3 -m pytest tests/test_gpu_bvhbuild.py tests/test_gpu_kdbuild.py -m gpu -q -s -k "report or built_on_the_device" > $out/builders.txt 2>&1
+python3 tools/builders.py 2>/dev/null | grep -E "^(lowres|hires|stress|stress8) " >> $out/builders.txt
 tools/kernel_resources.sh > $out/kernel_resources.txt 2>&1
 echo "all done"
