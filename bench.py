@@ -536,7 +536,11 @@ def main():
                        "exchange": exchange, "assemble_ms": assemble_ms,
                        "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_ms_min_over_ranks": kernel_ms_min,
                        "rays_per_frame": rays_per_frame, "samples_per_frame": tot[4],
-                       "knn_queries_per_frame": tot[5]},
+                       "knn_queries_per_frame": tot[5],
+                       # (outside the timed region: the scene's tree, who built it and how long rt_create's build took)
+                       "bvh": {"builder": {1: "device", 2: "hybrid", 3: "host"}.get(ctx.bvh_info().builder, "host"),
+                               "build_ms": ctx.bvh_info().build_ms, "nodes": ctx.bvh_info().n_nodes,
+                               "max_depth": ctx.bvh_info().max_depth}},
             "roofline": roof,
         }
         if tuned:
