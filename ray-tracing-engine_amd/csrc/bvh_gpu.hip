@@ -148,26 +148,27 @@ struct SubShared {
 template <int T>
 __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items, const uint32_t* __restrict__ scratchOff,
                                                uint32_t* __restrict__ order, const float4* __restrict__ triLo,
-                                               const float4* __restrict__ triHi, uint32_t leafMax, int depthCap,
+                                               const float4* __restrict__ triHi, const float* __restrict__ skey, uint32_t leafMax, int depthCap,
                                                float4* __restrict__ scratch, uint32_t* __restrict__ cntOut,
                                                uint32_t* __restrict__ heightOut) {
   static_assert(T <= 1024 && (T & (T - 1)) == 0, "positions are 10-bit payloads of the sort keys; the bitonic network wants a power of two");
   extern __shared__ unsigned long long sub_lds[];
-  // LDS carve-up (T = 1024: 8 + 8 + 36 + 4 + 24 + 4 + 6 + 10 KB = 100 KB)
+  // LDS carve-up (T = 1024: 8 + 8 + 40 + 4 + 24 + 4 + 8 + 12 KB = 108 KB)
   unsigned long long* key = sub_lds;                  // [T] sort keys
   unsigned long long* best = key + T;                 // [T] per segment start: (cost bits << 32 | axis << 16 | split position)
   float* eLo = reinterpret_cast<float*>(best + T);    // [3][T] element boxes, centroids (position order)
   float* eHi = eLo + 3 * T;
-  float* eCen = eHi + 3 * T;
-  uint32_t* eTid = reinterpret_cast<uint32_t*>(eCen + 3 * T);  // [T] triangle (reference index)
+  float* eCen = eHi + 3 * T;                          // [4][T]: [3] = the size key (bvh_build.cpp Prim::c[3]), the fourth sweep axis
+  uint32_t* eTid = reinterpret_cast<uint32_t*>(eCen + 4 * T);  // [T] triangle (reference index)
   float* sc = reinterpret_cast<float*>(eTid + T);     // [6][T] scan buffer
   float* sufA = sc + 6 * T;                           // [T] area of the suffix box
-  uint16_t* rnk = reinterpret_cast<uint16_t*>(sufA + T);  // [3][T] rank of each position along each axis
-  uint16_t* segS = rnk + 3 * T;                       // [T] segment [segS, segE) of the element at this position
+  uint16_t* rnk = reinterpret_cast<uint16_t*>(sufA + T);  // [4][T] rank of each position along each axis
+  uint16_t* segS = rnk + 4 * T;                       // [T] segment [segS, segE) of the element at this position
   uint16_t* segE = segS + T;
   uint16_t* segNode = segE + T;                       // [T] local node index of the segment (all its positions carry it)
   uint16_t* segDep = segNode + T;                     // [T] depth of that node
   uint16_t* scan16 = segDep + T;                      // [T] flag scan
+  uint16_t* idRank = scan16 + T;                      // [T] rank of the element's triangle id within the range: the host's tie-break
   __shared__ uint32_t nodeCount, anySplit, maxDep;
 
   const SubItem it = items[blockIdx.x];
@@ -180,10 +181,26 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
     eLo[i] = l.x, eLo[T + i] = l.y, eLo[2 * T + i] = l.z;
     eHi[i] = h.x, eHi[T + i] = h.y, eHi[2 * T + i] = h.z;
     eCen[i] = 0.5f * l.x + 0.5f * h.x, eCen[T + i] = 0.5f * l.y + 0.5f * h.y, eCen[2 * T + i] = 0.5f * l.z + 0.5f * h.z;
+    eCen[3 * T + i] = skey[t];
     eTid[i] = t;
   }
   segS[i] = 0, segE[i] = (uint16_t)n, segNode[i] = 0, segDep[i] = (uint16_t)it.depth;
   if (i == 0) nodeCount = 1u, maxDep = it.depth;
+  // the host builder's sorts break ties by triangle id (bvh_build.cpp split(): (key, id) is a total order): every element
+  // carries the rank of its id within the range and the sort keys below hold it between the centroid and the position
+  key[i] = i < n ? ((unsigned long long)order[it.b + i] << 10) | i : ~0ull;
+  __syncthreads();
+  for (uint32_t k = 2; k <= (uint32_t)T; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t x = i ^ j;
+      if (x > i) {
+        const unsigned long long ka = key[i], kb = key[x];
+        const bool up = (i & k) == 0;
+        if ((ka > kb) == up) key[i] = kb, key[x] = ka;
+      }
+      __syncthreads();
+    }
+  if (i < n) idRank[(uint32_t)(key[i] & 1023u)] = (uint16_t)i;
   __syncthreads();
 
   auto gather_boxes = [&](bool) {
@@ -219,14 +236,14 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
     if (big && i == segS[i]) anySplit = 1u;
     __syncthreads();
     if (!anySplit) break;
-    // ---- the three sweeps
-    for (int a = 0; a < 3; ++a) {
+    // ---- the four sweeps (three centroid axes and the size key, as bvh_build.cpp split() below kSweepMax)
+    for (int a = 0; a < 4; ++a) {
       uint32_t ck = 0;
       if (i < n) {
         const int fk = fkey(eCen[a * T + i]);
         ck = (uint32_t)fk ^ 0x80000000u;  // order-preserving unsigned
       }
-      key[i] = i < n ? ((unsigned long long)segS[i] << 42) | ((unsigned long long)ck << 10) | i : ~0ull;
+      key[i] = i < n ? ((unsigned long long)segS[i] << 52) | ((unsigned long long)ck << 20) | ((unsigned long long)idRank[i] << 10) | i : ~0ull;
       __syncthreads();
       for (uint32_t k = 2; k <= (uint32_t)T; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -253,9 +270,12 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
         const uint32_t s0 = segS[i], nl = i + 1u - s0, nr = segE[i] - i - 1u;
         const int rem = depthCap - (int)segDep[i] - 1;
         const unsigned long long maxSide = rem >= 31 ? ~0ull : (unsigned long long)leafMax << (rem < 0 ? 0 : rem);
-        if (nl <= maxSide && nr <= maxSide) {
-          const float cost = area_at(i) * (float)((nl + leafMax - 1u) / leafMax) + sufA[i + 1u] * (float)((nr + leafMax - 1u) / leafMax);
-          if (cost == cost && cost >= 0.f)
+        // (the size axis only where the segment's keys differ — sorted: its first and last key — and at 1.5 x its cost)
+        const bool axisOn = a < 3 || ((key[s0] >> 20) & 0xffffffffull) != ((key[segE[i] - 1u] >> 20) & 0xffffffffull);
+        if (axisOn && nl <= maxSide && nr <= maxSide) {
+          float cost = area_at(i) * (float)((nl + leafMax - 1u) / leafMax) + sufA[i + 1u] * (float)((nr + leafMax - 1u) / leafMax);
+          if (a == 3) cost *= 1.5f;
+          if (cost == cost && cost >= 0.f && cost < inf)
             atomicMin(&best[s0], ((unsigned long long)__float_as_uint(cost) << 32) | ((unsigned long long)a << 16) | (i + 1u));
         }
       }
@@ -266,22 +286,24 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
     uint32_t ax = 0, kpos = 0;
     if (big) {
       const unsigned long long bb = best[segS[i]];
-      if (bb == ~0ull) ax = 3u, kpos = segS[i] + (uint32_t)(segE[i] - segS[i]) / 2u;
-      else ax = (uint32_t)(bb >> 16) & 3u, kpos = (uint32_t)bb & 0xffffu;
+      if (bb == ~0ull) ax = 4u, kpos = segS[i] + (uint32_t)(segE[i] - segS[i]) / 2u;
+      else ax = (uint32_t)(bb >> 16) & 7u, kpos = (uint32_t)bb & 0xffffu;
     }
-    // ---- every triangle to its rank along the chosen axis (ax == 3: stays)
-    const uint32_t np = (big && ax < 3u) ? rnk[ax * T + i] : i;
-    float m[9];
+    // ---- every triangle to its rank along the chosen axis (ax == 4: stays)
+    const uint32_t np = (big && ax < 4u) ? rnk[ax * T + i] : i;
+    float m[10];
     uint32_t mt = 0;
-    uint16_t ms = 0, me = 0, mn = 0, md = 0;
+    uint16_t ms = 0, me = 0, mn = 0, md = 0, mr = 0;
     if (i < n) {
       for (int c = 0; c < 3; ++c) m[c] = eLo[c * T + i], m[3 + c] = eHi[c * T + i], m[6 + c] = eCen[c * T + i];
-      mt = eTid[i], ms = segS[i], me = segE[i], mn = segNode[i], md = segDep[i];
+      m[9] = eCen[3 * T + i];
+      mt = eTid[i], ms = segS[i], me = segE[i], mn = segNode[i], md = segDep[i], mr = idRank[i];
     }
     __syncthreads();
     if (i < n) {
       for (int c = 0; c < 3; ++c) eLo[c * T + np] = m[c], eHi[c * T + np] = m[3 + c], eCen[c * T + np] = m[6 + c];
-      eTid[np] = mt;
+      eCen[3 * T + np] = m[9];
+      eTid[np] = mt, idRank[np] = mr;
       // the new segment of this triangle, its parent's node and which child it is (in segNode's high bit for now)
       if (big) {
         const bool right = np >= kpos;
@@ -353,7 +375,7 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
   }
 }
 
-constexpr size_t subtree_lds_bytes(int T) { return (size_t)T * (8 + 8 + 36 + 4 + 24 + 4 + 6 + 12); }
+constexpr size_t subtree_lds_bytes(int T) { return (size_t)T * (8 + 8 + 40 + 4 + 24 + 4 + 8 + 12); }
 
 // scratch -> final arrays: subtree i's nodes go to [base[i], base[i] + cnt[i]), inner refs shifted, boxes padded
 // and packed; the top node that refers to the subtree gets its root's index.
@@ -1174,7 +1196,7 @@ struct Arena {
 // same packed, `subs` the parts; builds every part's exact subtree, numbers them behind the top, runs the rotation passes
 // and the final numbering / packing, and writes the triangle records.  Outputs as gpu_bvh_build.
 static hipError_t subtrees_and_finish(const float* dVpos, const uint4* dTriShade, uint32_t n, uint32_t nTop, uint32_t nSub,
-                                      const SubItem* subs, uint32_t* order, const float4* lo, const float4* hi, uint32_t leafMax,
+                                      const SubItem* subs, uint32_t* order, const float4* lo, const float4* hi, const float* skey, uint32_t leafMax,
                                       int depthCap, float pad, float boxScale, uint32_t topMaxDepth, uint32_t maxNodes, float4* nodesF,
                                       uint4* nodes16, float4* tris, float4* trisRef, uint32_t* nTotalOut, uint32_t* maxDepthOut,
                                       hipStream_t stream) {
@@ -1207,7 +1229,7 @@ static hipError_t subtrees_and_finish(const float* dVpos, const uint4* dTriShade
     const size_t ldsBytes = subtree_lds_bytes((int)kSubMax);
     static std::atomic<unsigned long long> ldsSet{0};
     SF_TRY(grant_lds(reinterpret_cast<const void*>(&k_subtree<(int)kSubMax>), ldsBytes, ldsSet));
-    hipLaunchKernelGGL((k_subtree<(int)kSubMax>), dim3(nSub), dim3(kSubMax), ldsBytes, stream, subs, scratchOff, order, lo, hi, leafMax,
+    hipLaunchKernelGGL((k_subtree<(int)kSubMax>), dim3(nSub), dim3(kSubMax), ldsBytes, stream, subs, scratchOff, order, lo, hi, skey, leafMax,
                        depthCap, scratch, subNodes, height);
     SF_TRY(rocprim::exclusive_scan(tmp, scanBytes, subNodes, finalOff, 0u, (size_t)nSub, rocprim::plus<uint32_t>(), stream));
     hipLaunchKernelGGL(k_sub_relocate, dim3(nSub), blk, 0, stream, subs, scratchOff, subNodes, finalOff, nTop, scratch, pad, boxScale,
@@ -1252,9 +1274,10 @@ static hipError_t subtrees_and_finish(const float* dVpos, const uint4* dTriShade
 // choices down to parts of <= kSubMax triangles) and, below it, the exact subtrees of step 6 — one workgroup per part.
 // The host spends most of a build in those bottom levels (sorts of every range of <= 4,096 triangles along four axes);
 // the top is a few binned passes.  Same arrays out as gpu_bvh_build.
-hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, uint32_t n, const rtbvh::TopBuilt& top, GpuBvh* out,
-                                  hipStream_t stream) {
+hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, const float* hSizeKey, uint32_t n, const rtbvh::TopBuilt& top,
+                                  GpuBvh* out, hipStream_t stream) {
   *out = GpuBvh{};
+  if (!hSizeKey) return hipErrorInvalidValue;
   const uint32_t nTop = (uint32_t)top.nodes.size(), nSub = (uint32_t)top.parts.size();
   if (n == 0 || nTop == 0 || top.order.size() != n) return hipErrorInvalidValue;
   for (const rtbvh::TopBuilt::Part& p : top.parts)
@@ -1263,7 +1286,7 @@ hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, ui
   const size_t nS = nSub ? nSub : 1u;
   Arena A;
   const size_t oLo = A.reserve((size_t)n * sizeof(float4)), oHi = A.reserve((size_t)n * sizeof(float4)), oOrd = A.reserve((size_t)n * 4),
-               oSubs = A.reserve(nS * sizeof(SubItem));
+               oSubs = A.reserve(nS * sizeof(SubItem)), oKey = A.reserve((size_t)n * 4);
   float4 *nodesF = nullptr, *tris = nullptr, *trisRef = nullptr;
   uint4* nodes16 = nullptr;
   bool keepOutputs = false;
@@ -1281,7 +1304,9 @@ hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, ui
   float4 *lo = A.at<float4>(oLo), *hi = A.at<float4>(oHi);
   uint32_t* order = A.at<uint32_t>(oOrd);
   SubItem* subs = A.at<SubItem>(oSubs);
+  float* skey = A.at<float>(oKey);
   GB_TRY(hipMemcpyAsync(order, top.order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  GB_TRY(hipMemcpyAsync(skey, hSizeKey, (size_t)n * 4, hipMemcpyHostToDevice, stream));
   // the top's records, float and packed (the packing of rtbvh::packNodes; part refs are patched in by k_sub_relocate)
   std::vector<rtbvh::Node16> top16(nTop);
   for (uint32_t i = 0; i < nTop; ++i) {
@@ -1307,7 +1332,7 @@ hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, ui
   hipLaunchKernelGGL(k_tri_boxes, dim3((n + 255) / 256), dim3(256), 0, stream, dVpos, dTriShade, n, lo, hi);
   GB_TRY(hipStreamSynchronize(stream));  // (the host vectors above go out of scope)
   uint32_t nTotal = 0, maxDepth = 0;
-  GB_TRY(subtrees_and_finish(dVpos, dTriShade, n, nTop, nSub, subs, order, lo, hi, top.leafMax, top.depthCap, top.pad, top.boxScale, top.maxDepth,
+  GB_TRY(subtrees_and_finish(dVpos, dTriShade, n, nTop, nSub, subs, order, lo, hi, skey, top.leafMax, top.depthCap, top.pad, top.boxScale, top.maxDepth,
                              maxNodes, nodesF, nodes16, tris, trisRef, &nTotal, &maxDepth, stream));
   keepOutputs = true;
   out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;
@@ -1473,7 +1498,7 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
   if (nTop) hipLaunchKernelGGL(k_rot_pack, dim3((nTop + 255) / 256), blk, 0, stream, nodes, nTop, P.boxScale, nodes16);
   const double tTop = msSince();
   uint32_t nTotal = 0, maxDepth = 0;
-  GB_TRY(subtrees_and_finish(dVpos, dTriShade, n, nTop, nSub, subs, ord, lo, hi, leafMax, P.depthCap, P.pad, P.boxScale, topMaxDepth, maxNodes,
+  GB_TRY(subtrees_and_finish(dVpos, dTriShade, n, nTop, nSub, subs, ord, lo, hi, skey, leafMax, P.depthCap, P.pad, P.boxScale, topMaxDepth, maxNodes,
                              nodesF, nodes16, tris, trisRef, &nTotal, &maxDepth, stream));
   keepOutputs = true;
   out->nodes16 = nodes16, out->nodesF = nodesF, out->tris = tris, out->trisRef = trisRef;

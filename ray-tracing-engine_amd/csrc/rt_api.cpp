@@ -473,6 +473,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
                 std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count());
       c->bvh.leafMax = topBuilt.leafMax, c->bvh.pad = topBuilt.pad, c->bvh.originBound = topBuilt.originBound, c->bvh.boxScale = topBuilt.boxScale;
       c->bvh.depthCap = topBuilt.depthCap;
+      (void)rtbvh::planSceneExact(*sc, opt ? opt->bvh_leaf_max : 0, sizeKey);  // (the size keys of the subtrees' sweeps)
     } else if (gpuBuild) {
       // (the device build restates the host builder's splits: it takes the host's depth cap and size keys)
       plan = rtbvh::planSceneExact(*sc, opt ? opt->bvh_leaf_max : 0, sizeKey);
@@ -516,7 +517,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     hipError_t he = hipSuccess;
     bool fellBack = false;
     if (hybrid) {
-      he = rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sc->n_triangles, topBuilt, &G, nullptr);
+      he = rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sizeKey.data(), sc->n_triangles, topBuilt, &G, nullptr);
     } else {
       bool needHost = false;
       he = rtk::gpu_bvh_build_exact(S.vpos, S.triShade, sizeKey.data(), sc->n_triangles, plan, &G, &needHost, nullptr);
@@ -529,7 +530,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
           return fail(RT_ERR_INVALID, "scene rejected: %s", e.what());
         }
         c->bvh.depthCap = topBuilt.depthCap;
-        he = rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sc->n_triangles, topBuilt, &G, nullptr);
+        he = rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sizeKey.data(), sc->n_triangles, topBuilt, &G, nullptr);
         fellBack = true;
         if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "exact device build: a range needs the host's median split; hybrid build instead\n");
       }

@@ -125,8 +125,8 @@ struct GpuBvh {
 hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const float* hSizeKey, uint32_t n_tris, const rtbvh::ScenePlan& plan,
                                GpuBvh* out, bool* needHost, hipStream_t stream);
 // the hybrid build: the host builder's top (rtbvh::buildTop), exact subtrees of its parts on the device
-hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, uint32_t n_tris, const rtbvh::TopBuilt& top, GpuBvh* out,
-                                  hipStream_t stream);
+hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, const float* hSizeKey, uint32_t n_tris, const rtbvh::TopBuilt& top,
+                                  GpuBvh* out, hipStream_t stream);
 // photon map on the device (kd_build.hip)
 hipError_t launch_photon_compact(const float4* slots, uint32_t n, float4* items, uint32_t* count, hipStream_t stream);
 hipError_t launch_kd_build(float4* items, uint32_t n, int depthOverride, hipStream_t stream);
