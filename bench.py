@@ -296,6 +296,14 @@ def build_params(ctx, pyrt, args, w, h, spp, mode, nph, k, rank, world):
                             wavefront=args.integrator == "wavefront")
 
 
+def second_build_ms(pyrt, scene, local, args):
+    """rt_create's build time once the process is warm (rank 0, after the timed region)."""
+    c2 = pyrt.Context(scene, device=local, bvh_leaf_max=args.leaf)
+    ms = c2.bvh_info().build_ms
+    c2.close()
+    return ms
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -537,10 +545,11 @@ def main():
                        "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_ms_min_over_ranks": kernel_ms_min,
                        "rays_per_frame": rays_per_frame, "samples_per_frame": tot[4],
                        "knn_queries_per_frame": tot[5],
-                       # (outside the timed region: the scene's tree, who built it and how long rt_create's build took)
+                       # (outside the timed region: the scene's tree, who built it and how long rt_create's build took —
+                       # the process's first rt_create, which also loads the code objects, and a second one)
                        "bvh": {"builder": {1: "device", 2: "hybrid", 3: "host"}.get(ctx.bvh_info().builder, "host"),
-                               "build_ms": ctx.bvh_info().build_ms, "nodes": ctx.bvh_info().n_nodes,
-                               "max_depth": ctx.bvh_info().max_depth}},
+                               "build_ms_first_create": ctx.bvh_info().build_ms, "build_ms": second_build_ms(pyrt, scene, local, args),
+                               "nodes": ctx.bvh_info().n_nodes, "max_depth": ctx.bvh_info().max_depth}},
             "roofline": roof,
         }
         if tuned:

@@ -87,10 +87,10 @@ enum { RT_TRACE_CLOSEST = 0, RT_TRACE_ANY = 1 };
 typedef struct rt_options {
   int32_t device;          /* HIP device ordinal                              */
   uint32_t bvh_leaf_max;   /* 0 = default (2), max 8                          */
-  uint32_t bvh_builder;    /* RT_BVH_*; AUTO = the device builder for scenes of 131,072 triangles and
-                              more (the same tree as the host builder's, 8-14 x sooner), the host
-                              builder below (its node order feeds the LDS-resident tree top).  The
-                              environment variable RT_BVH_GPU=1|2|3 forces DEVICE | HYBRID | HOST   */
+  uint32_t bvh_builder;    /* RT_BVH_*; AUTO = the device builder for scenes of 8,192 triangles and
+                              more (the same tree as the host builder's, 2-14 x sooner), the host
+                              builder below (1-3 ms either way).  The environment variable
+                              RT_BVH_GPU=1|2|3 forces DEVICE | HYBRID | HOST                        */
   uint32_t node_format;    /* RT_NODES_*: the node records the pooled render kernel and rt_trace
                               traverse.  AUTO picks per scene; the hits are the same either way  */
   uint32_t reserved[4];

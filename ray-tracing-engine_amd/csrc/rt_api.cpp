@@ -454,10 +454,11 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     delete c;
     return fail(RT_ERR_INVALID, "unknown bvh_builder %u", wantBuilder);
   }
-  // AUTO: the device builder gives the host builder's tree (same node visits, same frame time: profiles/r04_builders.txt)
-  // 8 x sooner, so big scenes take it; trees that fit the LDS-resident top keep the host builder, whose node ORDER (most
-  // visited first) that top is cut from, and a group of contexts shares one host-built tree
-  if (wantBuilder == RT_BVH_AUTO) wantBuilder = (sc->n_triangles >= 131072u && !prebuilt) ? (uint32_t)RT_BVH_DEVICE : (uint32_t)RT_BVH_HOST;
+  // AUTO: the device builder gives the host builder's tree (tests/treedigest.py; profiles/r04_builders.txt) 2 ... 14 x sooner,
+  // so every scene it is faster on takes it (from 8,192 triangles: below that a build is 1-3 ms either way and the host needs no
+  // device round trip); a group of contexts given a host-built tree shares it
+  static const uint32_t autoFrom = getenv("RT_BVH_AUTO_FROM") ? (uint32_t)atoi(getenv("RT_BVH_AUTO_FROM")) : 8192u;
+  if (wantBuilder == RT_BVH_AUTO) wantBuilder = (sc->n_triangles >= autoFrom && !prebuilt) ? (uint32_t)RT_BVH_DEVICE : (uint32_t)RT_BVH_HOST;
   // (a scene of a single part has no top to build on the host: the device builder's own path handles it)
   const bool hybrid = wantBuilder == RT_BVH_HYBRID && sc->n_triangles > 1024u;
   const bool gpuBuild = (wantBuilder == RT_BVH_DEVICE || wantBuilder == RT_BVH_HYBRID) && sc->n_triangles >= 16;
@@ -545,6 +546,24 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     c->bvh.maxDepth = G.maxDepth;
     S.n_nodes = G.n_nodes;
     c->builder = (hybrid || fellBack) ? RT_BVH_HYBRID : RT_BVH_DEVICE;
+    // Trees whose top the render kernel may keep in LDS (rt_kernels.hip plan_persist: a prefix of the node array) get the host
+    // builder's final numbering — the most-visited nodes first, greedily by box area from the root (bvh_build.cpp
+    // relayoutTop) — instead of the device's pre-order: C4 loses 2 % on a pre-order tree.  64 KB ... 4 MB back and forth.
+    if (S.n_nodes >= 2u && S.n_nodes <= 65536u) {
+      try {
+        c->bvh.nodes.resize(S.n_nodes);
+        if (hipMemcpy(c->bvh.nodes.data(), c->dNodesF, (size_t)S.n_nodes * sizeof(rtbvh::Node), hipMemcpyDeviceToHost) != hipSuccess)
+          throw std::runtime_error("reading the device-built tree back failed");
+        rtbvh::relayoutAndPack(c->bvh);
+        if (hipMemcpy(c->dNodesF, c->bvh.nodes.data(), (size_t)S.n_nodes * sizeof(rtbvh::Node), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(const_cast<uint4*>(S.nodes), c->bvh.nodes16.data(), (size_t)S.n_nodes * sizeof(rtbvh::Node16), hipMemcpyHostToDevice) != hipSuccess)
+          throw std::runtime_error("writing the renumbered tree failed");
+        c->bvh.nodes.clear(), c->bvh.nodes16.clear();  // (rt_bvh_export reads the device copies)
+      } catch (const std::exception& e) {
+        rt_destroy(c);
+        return fail(RT_ERR_HIP, "device BVH build: %s", e.what());
+      }
+    }
   } else {
     UP(nodes, c->bvh.nodes16.data(), c->bvh.nodes16.size() * 2);
     UP(tris, c->bvh.tris.data(), c->bvh.tris.size() * 3);

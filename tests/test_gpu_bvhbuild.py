@@ -1,5 +1,5 @@
 """The BVH built on the device (csrc/bvh_gpu.hip, rt_options.bvh_builder = RT_BVH_DEVICE — what RT_BVH_AUTO takes from
-131,072 triangles): the host builder's split rules as kernels.  Same arrays, same exactness bar as the host SAH builder —
+8,192 triangles): the host builder's split rules as kernels.  Same arrays, same exactness bar as the host SAH builder —
 BVH == exhaustive loop == oracle on all four scenes — plus the structural invariants, the depth cap, determinism, and the
 claim itself: the HOST builder's tree (node count, depth, node visits and triangle tests per ray), in a fraction of its
 time.  (The whole GPU suite also runs on device-built trees with RT_BVH_GPU=1.)"""
