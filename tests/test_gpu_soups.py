@@ -50,3 +50,25 @@ def test_frames_on_hard_soups_agree_across_builders(kind):
         ctx.close()
     for f in frames[1:]:
         assert np.array_equal(f[0].view(np.uint32), frames[0][0].view(np.uint32)) and f[1:] == frames[0][1:]
+
+
+@pytest.mark.parametrize("leaf", [1, 3, 8])
+def test_device_builder_with_other_leaf_sizes(leaf):
+    """rt_options.bvh_leaf_max 1 ... 8 through the device builder (parts, top leaves and the depth budget all depend on it):
+    exact, and the same tree as the host builder's."""
+    from treedigest import context_digest
+    for s in (pyrt.Scene("hires", 16, 16), soups.soup("random", 20000)):
+        rays = soups.soup_rays(s, 2000) if isinstance(s, pyrt.ArrayScene) else None
+        got = {}
+        for builder in (pyrt.BVH_HOST, pyrt.BVH_DEVICE):
+            ctx = pyrt.Context(s, bvh_leaf_max=leaf, bvh_builder=builder)
+            bi = ctx.bvh_info()
+            assert bi.leaf_max == leaf and bi.max_depth < 32
+            if rays is not None:
+                want = ctx.trace(rays, pyrt.ACCEL_BRUTE)
+                assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BVH).view(np.uint8), want.view(np.uint8)), (leaf, builder)
+            got[builder] = (context_digest(ctx), bi.n_nodes, bi.max_depth)
+            ctx.close()
+        import os
+        if not os.environ.get("RT_BVH_GPU"):
+            assert got[pyrt.BVH_DEVICE] == got[pyrt.BVH_HOST], (leaf, got)
