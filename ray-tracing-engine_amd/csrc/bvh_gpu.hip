@@ -1409,9 +1409,10 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
   std::vector<uint32_t> hBlk, hSweep, hMid;
   std::vector<int32_t> hRefs;
   uint32_t nTop = 1, nSub = 0, depth = 0, topMaxDepth = 0;
+  const SubItem whole{0u, n, 0u, ~0u, 0u};
   if (n <= kSubMax) {  // the whole scene is one exact subtree: no top
-    const SubItem whole{0u, n, 0u, ~0u, 0u};
-    GB_TRY(hipMemcpy(subs, &whole, sizeof whole, hipMemcpyHostToDevice));
+    GB_TRY(hipMemcpyAsync(subs, &whole, sizeof whole, hipMemcpyHostToDevice, stream));
+    GB_TRY(hipStreamSynchronize(stream));
     cur.clear(), nTop = 0, nSub = 1;
   }
   while (!cur.empty()) {
@@ -1436,9 +1437,9 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
       cleanup();
       return hipErrorInvalidValue;
     }
-    GB_TRY(hipMemcpy(items, hItems.data(), (size_t)count * sizeof(TopItem), hipMemcpyHostToDevice));
-    GB_TRY(hipMemcpy(blkItem, hBlk.data(), (size_t)nBlk * 4, hipMemcpyHostToDevice));
-    if (nSweep) GB_TRY(hipMemcpy(sweepList, hSweep.data(), (size_t)nSweep * 4, hipMemcpyHostToDevice));
+    GB_TRY(hipMemcpyAsync(items, hItems.data(), (size_t)count * sizeof(TopItem), hipMemcpyHostToDevice, stream));
+    GB_TRY(hipMemcpyAsync(blkItem, hBlk.data(), (size_t)nBlk * 4, hipMemcpyHostToDevice, stream));
+    if (nSweep) GB_TRY(hipMemcpyAsync(sweepList, hSweep.data(), (size_t)nSweep * 4, hipMemcpyHostToDevice, stream));
     const dim3 grdI((count + 255) / 256);
     hipLaunchKernelGGL(k_top_init, dim3((count * 12u + 255u) / 256u), blk, 0, stream, count, ib, cbx);
     hipLaunchKernelGGL(k_top_bounds, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, skey, ib);
@@ -1486,10 +1487,11 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
       cleanup();
       return hipErrorInvalidValue;
     }
-    GB_TRY(hipMemcpy(refs, hRefs.data(), 2 * (size_t)count * 4, hipMemcpyHostToDevice));
+    GB_TRY(hipMemcpyAsync(refs, hRefs.data(), 2 * (size_t)count * 4, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_top_childbox, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, mid, cbx);
     hipLaunchKernelGGL(k_top_emit, grdI, blk, 0, stream, items, count, depth, mid, refs, cbx, P.pad, ord, nodes, subs);
-    // (the next level's uploads overwrite `items` and `refs`: the kernels above must have read them)
+    // (the next level's uploads overwrite `items` and `refs` — and the host vectors they come from —: the kernels above must
+    // have read them)
     GB_TRY(hipStreamSynchronize(stream));
     cur.swap(next);
     ++depth;
