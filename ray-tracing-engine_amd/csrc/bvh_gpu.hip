@@ -801,11 +801,14 @@ __global__ __launch_bounds__(256) void k_top_bins(const TopItem* __restrict__ it
 __device__ __forceinline__ Box3 top_box_of(const int* B) {
   return Box3{funkey(B[0]), funkey(B[1]), funkey(B[2]), funkey(B[3]), funkey(B[4]), funkey(B[5])};
 }
-// the binned SAH choice of bvh_build.cpp split(), one thread per range (a few hundred operations)
-__global__ void k_top_choose(const TopItem* __restrict__ items, uint32_t count, uint32_t depth, int depthCap, uint32_t leafMax,
-                             const TopPrep* __restrict__ prep, const int* __restrict__ bins, TopDec* __restrict__ dec,
-                             uint32_t* __restrict__ mid, uint32_t* __restrict__ needHost) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+// the binned SAH choice of bvh_build.cpp split(): one WAVE per range, lane = bin.  The host walks the bins sequentially — a
+// suffix pass for the right boxes and counts, a prefix pass pricing the cut behind every bin, the first strict minimum in
+// axis-then-bin order —; box unions are min / max and the counts integers, so the scans give the same boxes, the same areas,
+// the same costs, and the wave picks the minimum of (cost, axis, bin) — the sequential loop's choice.
+__global__ __launch_bounds__(64) void k_top_choose(const TopItem* __restrict__ items, uint32_t count, uint32_t depth, int depthCap,
+                                                   uint32_t leafMax, const TopPrep* __restrict__ prep, const int* __restrict__ bins,
+                                                   TopDec* __restrict__ dec, uint32_t* __restrict__ mid, uint32_t* __restrict__ needHost) {
+  const uint32_t r = blockIdx.x, lane = threadIdx.x;
   if (r >= count) return;
   const TopItem it = items[r];
   if (it.nb == 0) return;
@@ -816,36 +819,55 @@ __global__ void k_top_choose(const TopItem* __restrict__ items, uint32_t count, 
   const unsigned long long maxSide = rem >= 31 ? ~0ull : (unsigned long long)leafMax << (rem < 0 ? 0 : rem);
   const int* G = bins + (size_t)it.binIdx * 4u * 64u * 7u;
   const float inf = __int_as_float(0x7f800000);
-  float bestCost = inf;
-  int bestAxis = -1, bestBin = -1;
+  unsigned long long best = ~0ull;  // cost bits << 32 | axis << 24 | bin << 16 ... (the left count rides separately)
   uint32_t bestLeft = 0;
   for (int ax = 0; ax < 4; ++ax) {
-    if (!((P.use >> ax) & 1u)) continue;
-    const int* A = G + 7 * (ax * 64);
-    float rightArea[64];
-    uint32_t rightCnt[64];
-    Box3 acc{inf, inf, inf, -inf, -inf, -inf};
-    uint32_t c = 0;
-    for (int k = NB - 1; k > 0; --k) {
-      acc = rot_union(acc, top_box_of(A + 7 * k)), c += (uint32_t)A[7 * k + 6];
-      rightArea[k] = half_area(acc), rightCnt[k] = c;
+    if (!((P.use >> ax) & 1u)) continue;  // (wave-uniform)
+    const bool in = (int)lane < NB;
+    const int* A = G + 7 * (ax * 64 + (in ? (int)lane : 0));
+    Box3 mine = in ? top_box_of(A) : Box3{inf, inf, inf, -inf, -inf, -inf};
+    uint32_t cnt = in ? (uint32_t)A[6] : 0u;
+    // inclusive prefix (bins 0 .. lane) and inclusive suffix (bins lane .. NB - 1) of boxes and counts
+    Box3 pre = mine, suf = mine;
+    uint32_t cpre = cnt, csuf = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+      const Box3 pb{__shfl_up(pre.lx, off, 64), __shfl_up(pre.ly, off, 64), __shfl_up(pre.lz, off, 64),
+                    __shfl_up(pre.hx, off, 64), __shfl_up(pre.hy, off, 64), __shfl_up(pre.hz, off, 64)};
+      const uint32_t pc = __shfl_up(cpre, off, 64);
+      if ((int)lane >= off) pre = rot_union(pre, pb), cpre += pc;
+      const Box3 sb{__shfl_down(suf.lx, off, 64), __shfl_down(suf.ly, off, 64), __shfl_down(suf.lz, off, 64),
+                    __shfl_down(suf.hx, off, 64), __shfl_down(suf.hy, off, 64), __shfl_down(suf.hz, off, 64)};
+      const uint32_t sc = __shfl_down(csuf, off, 64);
+      if ((int)lane + off < 64) suf = rot_union(suf, sb), csuf += sc;
     }
-    acc = Box3{inf, inf, inf, -inf, -inf, -inf}, c = 0;
-    for (int k = 0; k < NB - 1; ++k) {
-      acc = rot_union(acc, top_box_of(A + 7 * k)), c += (uint32_t)A[7 * k + 6];
-      if (c == 0 || rightCnt[k + 1] == 0 || c > maxSide || rightCnt[k + 1] > maxSide) continue;
-      float cost = half_area(acc) * ceilf(c / (float)leafMax) + rightArea[k + 1] * ceilf(rightCnt[k + 1] / (float)leafMax);
+    // the cut behind bin k = lane: left = bins 0 .. k, right = bins k + 1 .. NB - 1 (lane k + 1's suffix)
+    const float rArea = __shfl_down(half_area(suf), 1, 64);
+    const uint32_t rCnt = __shfl_down(csuf, 1, 64);
+    unsigned long long key = ~0ull;
+    if ((int)lane < NB - 1 && cpre != 0u && rCnt != 0u && cpre <= maxSide && rCnt <= maxSide) {
+      float cost = half_area(pre) * ceilf(cpre / (float)leafMax) + rArea * ceilf(rCnt / (float)leafMax);
       if (ax == 3) cost *= 1.5f;  // (bvh_build.cpp sizeBias)
-      if (cost < bestCost) bestCost = cost, bestAxis = ax, bestBin = k, bestLeft = c;
+      if (cost == cost && cost >= 0.f && cost < inf) key = ((unsigned long long)__float_as_uint(cost) << 32) | ((unsigned long long)ax << 8) | lane;
+    }
+    unsigned long long m = key;
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(m, off, 64);
+      m = o < m ? o : m;
+    }
+    if (m < best) {  // (strictly cheaper than every earlier axis' best, or the first)
+      best = m;
+      bestLeft = __shfl(cpre, (int)(m & 63u), 64);
     }
   }
+  if (lane != 0) return;
   // the host's median fall-backs: no admissible cut, or an extremely lopsided one deep in the tree
   const uint32_t small = bestLeft < n - bestLeft ? bestLeft : n - bestLeft;
-  if (bestAxis < 0 || (n > 64u && (unsigned long long)small * 64ull < n && (int)depth > rtbvh::kMaxDepth / 2)) {
+  if (best == ~0ull || (n > 64u && (unsigned long long)small * 64ull < n && (int)depth > rtbvh::kMaxDepth / 2)) {
     atomicExch(needHost, 1u);
     dec[r] = TopDec{-1, 0, 0.f, 0.f}, mid[r] = it.b + n / 2u;
     return;
   }
+  const int bestAxis = (int)((best >> 8) & 3u), bestBin = (int)(best & 63u);
   dec[r] = TopDec{bestAxis, bestBin, P.lo[bestAxis], P.scale[bestAxis]};
   mid[r] = it.b + bestLeft;
 }
@@ -1446,7 +1468,7 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
     hipLaunchKernelGGL(k_top_prep, grdI, blk, 0, stream, items, count, ib, prep, bins);
     if (nBinned) {
       hipLaunchKernelGGL(k_top_bins, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, skey, prep, bins);
-      hipLaunchKernelGGL(k_top_choose, grdI, blk, 0, stream, items, count, depth, P.depthCap, leafMax, prep, bins, dec, mid, flag);
+      hipLaunchKernelGGL(k_top_choose, dim3(count), dim3(64), 0, stream, items, count, depth, P.depthCap, leafMax, prep, bins, dec, mid, flag);
       hipLaunchKernelGGL(k_top_count, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, skey, dec, blockLeft);
       hipLaunchKernelGGL(k_top_offsets, dim3(count), dim3(64), 0, stream, items, blockLeft);
       hipLaunchKernelGGL(k_top_scatter, dim3(nBlk), blk, 0, stream, items, blkItem, ord, lo, hi, skey, dec, mid, blockLeft, tmp);
