@@ -153,7 +153,7 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
                                                uint32_t* __restrict__ heightOut) {
   static_assert(T <= 1024 && (T & (T - 1)) == 0, "positions are 10-bit payloads of the sort keys; the bitonic network wants a power of two");
   extern __shared__ unsigned long long sub_lds[];
-  // LDS carve-up (T = 1024: 8 + 8 + 40 + 4 + 24 + 4 + 8 + 12 KB = 108 KB)
+  // LDS carve-up (T = 1024: 8 + 8 + 40 + 4 + 24 + 4 + 8 + 12 + 8 KB = 116 KB)
   unsigned long long* key = sub_lds;                  // [T] sort keys
   unsigned long long* best = key + T;                 // [T] per segment start: (cost bits << 32 | axis << 16 | split position)
   float* eLo = reinterpret_cast<float*>(best + T);    // [3][T] element boxes, centroids (position order)
@@ -169,6 +169,9 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
   uint16_t* segDep = segNode + T;                     // [T] depth of that node
   uint16_t* scan16 = segDep + T;                      // [T] flag scan
   uint16_t* idRank = scan16 + T;                      // [T] rank of the element's triangle id within the range: the host's tie-break
+  uint16_t* ordA = idRank + T;                        // [4][T] per axis: the element (position) at each SORTED position — segment by segment
+  uint16_t* nph = reinterpret_cast<uint16_t*>(sufA);  // [T] (between the sweeps and the move) new position | big << 14 | right << 15
+  uint16_t* cl = nph + T;                             // [T] flag scan of the order updates
   __shared__ uint32_t nodeCount, anySplit, maxDep;
 
   const SubItem it = items[blockIdx.x];
@@ -202,10 +205,31 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
     }
   if (i < n) idRank[(uint32_t)(key[i] & 1023u)] = (uint16_t)i;
   __syncthreads();
+  // The range sorted along each of the four axes by (key, id) ONCE; a split keeps every axis' order inside both children
+  // (a stable partition of a sorted sequence), so the levels below re-use the orders instead of sorting again — 55 steps of
+  // a bitonic network per axis and level became one flag scan.
+  for (int a = 0; a < 4; ++a) {
+    uint32_t ck = 0;
+    if (i < n) ck = (uint32_t)fkey(eCen[a * T + i]) ^ 0x80000000u;  // order-preserving unsigned
+    key[i] = i < n ? ((unsigned long long)ck << 20) | ((unsigned long long)idRank[i] << 10) | i : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= (uint32_t)T; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        const uint32_t x = i ^ j;
+        if (x > i) {
+          const unsigned long long ka = key[i], kb = key[x];
+          const bool up = (i & k) == 0;
+          if ((ka > kb) == up) key[i] = kb, key[x] = ka;
+        }
+        __syncthreads();
+      }
+    ordA[a * T + i] = i < n ? (uint16_t)(key[i] & 1023u) : (uint16_t)0;
+    __syncthreads();
+  }
 
-  auto gather_boxes = [&](bool) {
-    // sc[c][i] = box component c of the element that sits at sorted position i (key payload = its home position)
-    const uint32_t h = i < n ? (uint32_t)(key[i] & 1023u) : 0u;
+  auto gather_boxes = [&](int a) {
+    // sc[c][i] = box component c of the element that sits at sorted position i of axis a
+    const uint32_t h = i < n ? (uint32_t)ordA[a * T + i] : 0u;
     for (int c = 0; c < 3; ++c) sc[c * T + i] = i < n ? eLo[c * T + h] : inf, sc[(3 + c) * T + i] = i < n ? eHi[c * T + h] : -inf;
   };
   auto scan_boxes = [&](bool suffix) {
@@ -238,31 +262,14 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
     if (!anySplit) break;
     // ---- the four sweeps (three centroid axes and the size key, as bvh_build.cpp split() below kSweepMax)
     for (int a = 0; a < 4; ++a) {
-      uint32_t ck = 0;
-      if (i < n) {
-        const int fk = fkey(eCen[a * T + i]);
-        ck = (uint32_t)fk ^ 0x80000000u;  // order-preserving unsigned
-      }
-      key[i] = i < n ? ((unsigned long long)segS[i] << 52) | ((unsigned long long)ck << 20) | ((unsigned long long)idRank[i] << 10) | i : ~0ull;
-      __syncthreads();
-      for (uint32_t k = 2; k <= (uint32_t)T; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-          const uint32_t x = i ^ j;
-          if (x > i) {
-            const unsigned long long ka = key[i], kb = key[x];
-            const bool up = (i & k) == 0;
-            if ((ka > kb) == up) key[i] = kb, key[x] = ka;
-          }
-          __syncthreads();
-        }
-      if (i < n) rnk[a * T + (uint32_t)(key[i] & 1023u)] = (uint16_t)i;
+      if (i < n) rnk[a * T + (uint32_t)ordA[a * T + i]] = (uint16_t)i;
       // suffix areas: sufA[j] = area of the box of sorted positions [j, segE)
-      gather_boxes(true);
+      gather_boxes(a);
       __syncthreads();
       scan_boxes(true);
       sufA[i] = area_at(i);
       __syncthreads();
-      gather_boxes(false);
+      gather_boxes(a);
       __syncthreads();
       scan_boxes(false);
       // the split AFTER sorted position i: left = [segS, i + 1), right = [i + 1, segE)
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
         const int rem = depthCap - (int)segDep[i] - 1;
         const unsigned long long maxSide = rem >= 31 ? ~0ull : (unsigned long long)leafMax << (rem < 0 ? 0 : rem);
         // (the size axis only where the segment's keys differ — sorted: its first and last key — and at 1.5 x its cost)
-        const bool axisOn = a < 3 || ((key[s0] >> 20) & 0xffffffffull) != ((key[segE[i] - 1u] >> 20) & 0xffffffffull);
+        const bool axisOn = a < 3 || eCen[3 * T + ordA[3 * T + segE[i] - 1u]] > eCen[3 * T + ordA[3 * T + s0]];
         if (axisOn && nl <= maxSide && nr <= maxSide) {
           float cost = area_at(i) * (float)((nl + leafMax - 1u) / leafMax) + sufA[i + 1u] * (float)((nr + leafMax - 1u) / leafMax);
           if (a == 3) cost *= 1.5f;
@@ -291,6 +298,34 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
     }
     // ---- every triangle to its rank along the chosen axis (ax == 4: stays)
     const uint32_t np = (big && ax < 4u) ? rnk[ax * T + i] : i;
+    // ---- the four orders follow: inside a split segment the lefts keep their order in front, the rights theirs behind (the
+    // segment arrays are still the old ones here: a sorted position belongs to the same segment on every axis)
+    __syncthreads();  // (sufA's last readers are done: nph / cl live there)
+    nph[i] = (uint16_t)(np | (big ? 0x4000u : 0u) | ((big && np >= kpos) ? 0x8000u : 0u));
+    __syncthreads();
+    for (int a = 0; a < 4; ++a) {
+      const uint32_t v = i < n ? (uint32_t)nph[ordA[a * T + i]] : 0u;
+      const bool bigP = (v & 0x4000u) != 0u, rightP = (v & 0x8000u) != 0u;
+      const uint32_t fl = (bigP && !rightP) ? 1u : 0u;
+      cl[i] = (uint16_t)fl;
+      __syncthreads();
+      for (uint32_t d = 1; d < (uint32_t)T; d <<= 1) {
+        const uint16_t add = (i < n && i >= d + segS[i]) ? cl[i - d] : (uint16_t)0;
+        __syncthreads();
+        cl[i] = (uint16_t)(cl[i] + add);
+        __syncthreads();
+      }
+      uint32_t newpos = i;
+      if (bigP) {
+        const uint32_t s0 = segS[i], before = (uint32_t)cl[i] - fl;  // lefts of this segment in front of this position
+        const unsigned long long bb = best[s0];
+        const uint32_t kp = bb == ~0ull ? s0 + (uint32_t)(segE[i] - s0) / 2u : (uint32_t)bb & 0xffffu;
+        newpos = rightP ? kp + (i - s0 - before) : s0 + before;
+      }
+      __syncthreads();
+      if (i < n) ordA[a * T + newpos] = (uint16_t)(v & 0x3ffu);
+      __syncthreads();
+    }
     float m[10];
     uint32_t mt = 0;
     uint16_t ms = 0, me = 0, mn = 0, md = 0, mr = 0;
@@ -375,7 +410,7 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
   }
 }
 
-constexpr size_t subtree_lds_bytes(int T) { return (size_t)T * (8 + 8 + 40 + 4 + 24 + 4 + 8 + 12); }
+constexpr size_t subtree_lds_bytes(int T) { return (size_t)T * (8 + 8 + 40 + 4 + 24 + 4 + 8 + 12 + 8); }
 
 // scratch -> final arrays: subtree i's nodes go to [base[i], base[i] + cnt[i]), inner refs shifted, boxes padded
 // and packed; the top node that refers to the subtree gets its root's index.
