@@ -72,3 +72,20 @@ def test_device_builder_with_other_leaf_sizes(leaf):
         import os
         if not os.environ.get("RT_BVH_GPU"):
             assert got[pyrt.BVH_DEVICE] == got[pyrt.BVH_HOST], (leaf, got)
+
+
+def test_device_builder_rejects_what_the_host_builder_rejects():
+    """Scenes big enough for RT_BVH_AUTO's device builder are validated by rtbvh::planSceneExact (the host builder's checks, on
+    several threads): a non-finite vertex or a triangle pointing outside its mesh fails rt_create with the same errors."""
+    s = soups.soup("random", 20000)
+    a = s.arrays()
+    bad = a["pos"].copy()
+    bad[31337, 2] = np.inf
+    with pytest.raises(pyrt.RtError) as e:
+        pyrt.Context(pyrt.ArrayScene(bad, a["nrm"], a["tri"], a["tri_begin"], a["vtx_begin"], a["materials"], a["lights"], a["camera"]))
+    assert e.value.code == 1 and "non-finite" in str(e.value)
+    tri = a["tri"].copy()
+    tri[19999, 1] = 60000
+    with pytest.raises(pyrt.RtError) as e:
+        pyrt.Context(pyrt.ArrayScene(a["pos"], a["nrm"], tri, a["tri_begin"], a["vtx_begin"], a["materials"], a["lights"], a["camera"]))
+    assert e.value.code == 1 and "outside its mesh" in str(e.value)
