@@ -194,6 +194,12 @@ constexpr int LT_COMPACT = 16;
 // holds the direction anyway; a lane that steals part of a bounce ray takes the direction from the
 // victim's registers.  The eight-million-triangle scene's sixteenth wave.
 constexpr int LT_COMPACT2 = 32;
+// ... and without the light samples' parameters either (implies LT_COMPACT2): the pixel lane keeps its RNG state from before
+// its light draws in a register and every use re-draws the sample from there — a worker lane fetches the state by lane
+// shuffle —: the same engine calls, the same bits.  360 words instead of 744: with the 25 stack rows of the 1 M-triangle tree
+// that is 7,840 B per wave — five workgroups of four waves fit a CU's LDS (which is handed out in 1,280-byte units: 8,096 B
+// per wave did not) —, TWENTY waves per CU, and the instance is compiled for five waves per SIMD (96 VGPRs).
+constexpr int LT_COMPACT3 = 64;
 // 1 / det of the triangle test by rtd::recip_fast (3 instructions, the division's bits for |det| < 2^100) instead of the
 // division: only the instances the launcher picks when the host has bounded |det| for the launch's rays (DevScene::slowRecip == 0).
 constexpr int LT_FASTDET = 256;
@@ -795,11 +801,12 @@ constexpr int VP_PT = 0, VP_DIR = 192, VP_BDIR = VP_DIR + 192 * POOL_L, VP_KEY =
 constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
 constexpr int VP_COMPACT_SAVES = 64 * POOL_L;  // words a compact pool is shorter by
 // offsets of everything behind the per-light block, by layout
-template <int CP> struct VpLayout {  // CP = 0: full, 1: light parameters, 2: ... and no bounce directions
+template <int CP> struct VpLayout {  // CP = 0: full, 1: light parameters, 2: ... and no bounce directions, 3: ... and one RNG word for the lights
   static constexpr int PER_LIGHT = CP ? 128 : 192;
-  static constexpr int BDIR = VP_DIR + PER_LIGHT * POOL_L, KEY = BDIR + (CP == 2 ? 0 : 192), LIST = KEY + 128, RES = LIST + 32;
+  static constexpr int BDIR = CP == 3 ? VP_DIR : VP_DIR + PER_LIGHT * POOL_L, KEY = BDIR + (CP >= 2 ? 0 : 192), LIST = KEY + 128, RES = LIST + 32;
   static constexpr int WORDS = RES + 2 * POOL_L + 2;
 };
+static_assert(VpLayout<3>::WORDS == (int)rtbvh::kWavePoolWordsMin && VpLayout<3>::KEY % 2 == 0, "the smallest pool (bvh_build.h sizes the depth cap with it)");
 static_assert(VpLayout<0>::WORDS == VP_WORDS && VpLayout<1>::WORDS == VP_WORDS - VP_COMPACT_SAVES &&
               VpLayout<2>::WORDS == VP_WORDS - 2 * VP_COMPACT_SAVES, "pool layouts");
 static_assert(VpLayout<1>::KEY % 2 == 0 && VpLayout<2>::KEY % 2 == 0, "64-bit keys need 8-byte alignment");
@@ -811,8 +818,8 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
                       f3& point, f3& bdir, uint32_t* stack, uint32_t* pool, HitRec& next, bool& nextFound, LaneStats& st) {
   constexpr bool FR = (LT & LT_FASTDET) != 0;  // 1 / length by rtd::recip_fast (see rtd::unit3)
   const uint32_t lane = threadIdx.x & 63u, nl = S.n_lights;
-  constexpr bool CP2 = (LT & LT_COMPACT2) != 0, CP = CP2 || (LT & LT_COMPACT) != 0;
-  using VP = VpLayout<CP2 ? 2 : CP ? 1 : 0>;
+  constexpr bool CP3 = (LT & LT_COMPACT3) != 0, CP2 = CP3 || (LT & LT_COMPACT2) != 0, CP = CP2 || (LT & LT_COMPACT) != 0;
+  using VP = VpLayout<CP3 ? 3 : CP2 ? 2 : CP ? 1 : 0>;
   float* fp = reinterpret_cast<float*>(pool);
   // 32 words: rank -> pixel lane (64 bytes) while rays are handed out; then rank -> victim
   // word while stealing (min(victims, free lanes) <= 32 entries)
@@ -824,6 +831,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   const uint32_t n = (uint32_t)__popcll(amask);
   f3 color = mk(0.f, 0.f, 0.f);
   nextFound = false;
+  uint32_t gsave = 0;  // (LT_COMPACT3) this lane's engine state before its light draws
   if (n == 0) return color;
   PH(PH_VSETUP);
   PHC(PH_N_POOLS);
@@ -831,8 +839,11 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
     fp[VP_PT + lane] = point.x, fp[VP_PT + 64 + lane] = point.y, fp[VP_PT + 128 + lane] = point.z;
     // draw order of the reference: the light samples in light order (Renderer.cpp:52),
     // then the hemisphere sample (Renderer.cpp:164)
+    if (CP3) gsave = g.s;  // (the light samples are re-drawn from here wherever they are needed)
     for (uint32_t l = 0; l < nl; l++) {
-      if (CP) {
+      if (CP3) {
+        g.next(), g.next();  // (light_sample_params' two engine calls)
+      } else if (CP) {
         float rh, rv;
         light_sample_params(g, S.lights[l], rh, rv);
         fp[VP_DIR + (2 * l + 0) * 64 + lane] = rh, fp[VP_DIR + (2 * l + 1) * 64 + lane] = rv;
@@ -953,13 +964,21 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       }
       PH(PH_STEAL);
     }
+    const uint32_t gsj = CP3 ? (uint32_t)__shfl((int)gsave, (int)newJ, 64) : 0u;  // (all lanes take part)
     if (newRay) {
       const f3 pj = mk(fp[VP_PT + newJ], fp[VP_PT + 64 + newJ], fp[VP_PT + 128 + newJ]);
       f3 dj;
       if (CP) {
         if (newK < nl) {  // rebuild the direction from the light sample's two parameters
           const rt_light& Lt = S.lights[newK];
-          const float rh = fp[VP_DIR + (2 * newK + 0) * 64 + newJ], rv = fp[VP_DIR + (2 * newK + 1) * 64 + newJ];
+          float rh, rv;
+          if (CP3) {  // ... which are re-drawn: the pixel lane's engine state before its light draws, 2 calls per earlier light
+            Rng t{gsj};
+            for (uint32_t q = 0; q < 2u * newK; ++q) t.next();
+            light_sample_params(t, Lt, rh, rv);
+          } else {
+            rh = fp[VP_DIR + (2 * newK + 0) * 64 + newJ], rv = fp[VP_DIR + (2 * newK + 1) * 64 + newJ];
+          }
           dj = light_point(Lt, rh, rv) - pj;
         } else if (CP2) {
           dj = newShared ? dv : bdir;  // a bounce ray: stolen (the victim's direction) or this lane's own
@@ -1011,10 +1030,14 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   if (bounce && !CP2) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
   if (alive) {
     const BsdfBase base = bsdf_base<FR>(S.matsDev[mesh], hitNormal, -rayDir);  // the light-independent half, once
+    Rng relight{gsave};
     for (uint32_t l = 0; l < nl; l++) {
+      float rh3 = 0.f, rv3 = 0.f;
+      if (CP3) light_sample_params(relight, S.lights[l], rh3, rv3);  // (every light: the stream moves on whether it is occluded or not)
       if ((res[l * 2 + (lane >> 5)] >> (lane & 31)) & 1u) continue;  // occluded (Renderer.cpp:54-55)
-      const f3 toLight = CP ? light_point(S.lights[l], fp[VP_DIR + (2 * l + 0) * 64 + lane], fp[VP_DIR + (2 * l + 1) * 64 + lane]) - pt
-                            : mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
+      const f3 toLight = CP3 ? light_point(S.lights[l], rh3, rv3) - pt
+                         : CP ? light_point(S.lights[l], fp[VP_DIR + (2 * l + 0) * 64 + lane], fp[VP_DIR + (2 * l + 1) * 64 + lane]) - pt
+                              : mk(fp[VP_DIR + (3 * l + 0) * 64 + lane], fp[VP_DIR + (3 * l + 1) * 64 + lane], fp[VP_DIR + (3 * l + 2) * 64 + lane]);
       const f3 bsdf = bsdf_apply<FR>(base, toLight);
       const f3 radiance = light_eval(S.lights[l], pt);
       color = color + radiance * bsdf;
@@ -1252,8 +1275,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_render(DevScene S, RenderArgs A
 // upper tree levels (all of them for the 1.2k-triangle scene) never touch the vector L1.
 // Waves never synchronise with each other after the tree copy.
 template <bool STATS, int LT>
-__global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs A, float4* __restrict__ accum,
-                                                         unsigned long long* __restrict__ counters) {
+RT_DEV void persist_body(const DevScene& S, const RenderArgs& A, float4* __restrict__ accum, unsigned long long* __restrict__ counters) {
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   {
     uint4* dst = reinterpret_cast<uint4*>(g_lds);
@@ -1282,6 +1304,20 @@ __global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs 
   if (threadIdx.x < PH_COUNT) atomicAdd(&counters[16 + threadIdx.x], g_phAcc[threadIdx.x]);
 #endif
   flush_stats(st, counters, STATS);
+}
+
+template <bool STATS, int LT>
+__global__ __launch_bounds__(1024) void k_render_persist(DevScene S, RenderArgs A, float4* __restrict__ accum,
+                                                         unsigned long long* __restrict__ counters) {
+  persist_body<STATS, LT>(S, A, accum, counters);
+}
+// The same for the trees that leave the LDS to the stacks (LT_COMPACT3: the 424-word pool): workgroups of FOUR waves, one per
+// SIMD, five of them per CU — 20 waves at 96 VGPRs (the compiler spills 28 registers, outside the descent: 1.4 % at equal
+// occupancy on the 1 M-triangle scene, against what the four extra waves hide of its memory latency).
+template <bool STATS, int LT>
+__global__ __launch_bounds__(256, 5) void k_render_persist5(DevScene S, RenderArgs A, float4* __restrict__ accum,
+                                                            unsigned long long* __restrict__ counters) {
+  persist_body<STATS, LT>(S, A, accum, counters);
 }
 
 // Renderer.cpp:262-265
@@ -1639,7 +1675,7 @@ static bool allow_big_lds(K kernel, unsigned long long& done) {
 // topK tree-top nodes in front of W private regions of waveWords each.  160 KiB per CU.
 struct PersistPlan {
   uint32_t waves, topK, waveWords, ldsBytes;
-  int compact = 0;  // 1: LT_COMPACT pool layout, 2: LT_COMPACT2
+  int compact = 0;  // 1: LT_COMPACT pool layout, 2: LT_COMPACT2, 3: LT_COMPACT3 (workgroups of 4 waves, 5 per CU)
 };
 static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   const uint32_t total = rtbvh::kLdsWordsPerCU;  // words
@@ -1656,6 +1692,17 @@ static PersistPlan plan_persist(const DevScene& S, const RenderArgs& A) {
   if (w * waveWords > total) return PersistPlan{0, 0, waveWords, 0};
   // big trees whose stacks leave fewer than 16 waves: the compact pool, if it buys a wave
   static const int cpEnv = getenv("RT_COMPACT") ? atoi(getenv("RT_COMPACT")) : -1;
+  // ... and if the smallest pool makes room for TWENTY waves (five workgroups of four per CU, 96 VGPRs): the 1 M-triangle
+  // scene's 25 stack rows + 424 words = 8,096 B per wave
+  if ((cpEnv < 0 || cpEnv == 3) && S.n_nodes > kPrioMaxNodes && !S.q8 && wEnv <= 0 && kEnv < 0) {
+    // (the LDS is handed out in units of 1,280 bytes: five workgroups of four waves must fit with their sizes rounded up)
+    const uint32_t ww3 = A.stackLevels * BLOCK + (uint32_t)VpLayout<3>::WORDS;
+    if (5u * ((16u * ww3 + rtbvh::kLdsGrainBytes - 1u) / rtbvh::kLdsGrainBytes * rtbvh::kLdsGrainBytes) <= 4u * total) {
+      PersistPlan cp{4u, 0u, ww3, 4u * 4u * ww3};
+      cp.compact = 3;
+      return cp;
+    }
+  }
   if (cpEnv != 0 && (S.n_nodes > kPrioMaxNodes || S.q8) && w < 16u && kEnv < 0) {
     // (the smallest step that buys the most waves; RT_COMPACT = 1 / 2 forces a level)
     uint32_t bestW = w;
@@ -1698,7 +1745,8 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
       hipError_t e = hipMemsetAsync(A.tileCounter, 0, sizeof(uint32_t), stream);
       if (e != hipSuccess) return e;
       const uint32_t perCU = P.waves;                                    // waves one workgroup brings
-      const uint32_t wgs = (blocks + perCU - 1) / perCU < A.numCUs ? (blocks + perCU - 1) / perCU : A.numCUs;
+      const uint32_t slots = P.compact == 3 ? 5u * A.numCUs : A.numCUs;  // workgroups the device holds at once
+      const uint32_t wgs = (blocks + perCU - 1) / perCU < slots ? (blocks + perCU - 1) / perCU : slots;
 #define RT_LAUNCH_PERSIST(ST, LTV)                                                                          \
   do {                                                                                                      \
     static unsigned long long done = 0;                                                                     \
@@ -1715,7 +1763,17 @@ static hipError_t launch_render2(bool stats, const DevScene& S, const RenderArgs
     else RT_LAUNCH_PERSIST(false, (LTV) | LT_FASTDET);           \
   } while (0)
       const int lt = P.topK == 0 ? LT_NONE : P.topK >= S.n_nodes ? LT_ALL : LT_TOP;
-      if (S.q8) {  // the one-request records (the context chose them: rt_api.cpp create_ctx)
+      if (P.compact == 3) {
+        static unsigned long long done5s = 0, done5t = 0;
+        if (stats || S.slowRecip) {
+          if (!allow_big_lds(&k_render_persist5<true, LT_NONE | LT_NOPRIO | LT_COMPACT3>, done5s)) return hipErrorInvalidConfiguration;
+          hipLaunchKernelGGL((k_render_persist5<true, LT_NONE | LT_NOPRIO | LT_COMPACT3>), dim3(wgs), dim3(256), P.ldsBytes, stream, S2, A2, accum, counters);
+        } else {
+          if (!allow_big_lds(&k_render_persist5<false, LT_NONE | LT_NOPRIO | LT_COMPACT3 | LT_FASTDET>, done5t)) return hipErrorInvalidConfiguration;
+          hipLaunchKernelGGL((k_render_persist5<false, LT_NONE | LT_NOPRIO | LT_COMPACT3 | LT_FASTDET>), dim3(wgs), dim3(256), P.ldsBytes, stream, S2, A2,
+                             accum, counters);
+        }
+      } else if (S.q8) {  // the one-request records (the context chose them: rt_api.cpp create_ctx)
         if (P.compact == 2) RT_LAUNCH_EITHER(LT_Q8 | LT_NOPRIO | LT_COMPACT2);
         else if (P.compact) RT_LAUNCH_EITHER(LT_Q8 | LT_NOPRIO | LT_COMPACT);
         else RT_LAUNCH_EITHER(LT_Q8 | LT_NOPRIO);
