@@ -91,8 +91,9 @@ PMC_PASSES = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_IN
 
 def is_timed_render_kernel(name):
     """The integrate kernel of the TIMED launches (not the one STATS pass)."""
-    if "k_render_persist<" in name:
-        return name.split("k_render_persist<")[1].split(">")[0].split(",")[0].strip() in ("false", "0")
+    for fam in ("k_render_persist<", "k_render_persist5<"):  # (the 16-wave workgroups, and the 4-wave ones of the 20-wave plan)
+        if fam in name:
+            return name.split(fam)[1].split(">")[0].split(",")[0].strip() in ("false", "0")
     if "k_render<" in name:
         return name.split("k_render<")[1].split(">")[0].split(",")[3].strip() in ("false", "0")
     return False

@@ -24,8 +24,8 @@ agg=collections.OrderedDict()
 for f in sorted(glob.glob(out+"/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]
-        if "k_render_persist<" in n:
-            if n.split("k_render_persist<")[1].split(">")[0].split(", ")[0] == "true": continue  # the STATS build
+        if "k_render_persist<" in n or "k_render_persist5<" in n:
+            if n.split("<")[1].split(">")[0].split(", ")[0] == "true": continue  # the STATS build
         elif "k_render<" in n:
             if n.split("k_render<")[1].split(">")[0].split(", ")[3] == "true": continue
         else: continue

@@ -23,7 +23,7 @@ for f in sorted(glob.glob(out+"/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]
         # the timed (STATS = false) render kernel: persistent pooled, or one-wave-per-workgroup (photon / brute / sequential)
-        timed = "k_render_persist<false" in n or ("k_render<" in n and n.split("k_render<")[1].split(">")[0].split(", ")[3] == "false")
+        timed = "k_render_persist<false" in n or "k_render_persist5<false" in n or ("k_render<" in n and n.split("k_render<")[1].split(">")[0].split(", ")[3] == "false")
         if not timed: continue
         agg.setdefault(r["Counter_Name"],[]).append(float(r["Counter_Value"]))
 for c,v in agg.items(): print("%-44s %.6g"%(c,v[-1]))
