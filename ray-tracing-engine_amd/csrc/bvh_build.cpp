@@ -1362,7 +1362,8 @@ void buildTop(const rt_scene_desc& sc, uint32_t leafMax, uint32_t cutoff, TopBui
   B.recurse(0, sc.n_triangles, 0, root, top);
   const double tSplit = msSince();
   out.nodes.swap(top.nodes);
-  smallerChildFirst(out.nodes);
+  // (slot 0 = the left range, as recurse() made it: the rotation passes — kernels, for this tree — run on the slot order build()'s
+  // own run on, and bvh_gpu.hip k_rot_pack puts the smaller box into slot 0 afterwards)
   relayoutTop(out.nodes, kTopNodes);
   // parts numbered by their place in the order (the threads registered them as they came), then their referrers
   std::vector<uint32_t> idx(B.parts.size());

@@ -109,11 +109,13 @@ constexpr bool fitsTwentyWaves(int depth) {
 // 15 / 14 waves = 402 / 415 / 416 / 393 ms with 37.5 / 36.7 / 36.7 / 35.0 node visits per ray; 8 M triangles (22 levels) +2 ... +5
 // all 14 waves = 73.3 / 71.7 / 71.8 / 63.9 ms, +6 (13 waves) 68.6 ms.  Round 4, with the 20-wave configuration: 1 M triangles at
 // 24 levels (+5) 276.9 ms on 20 waves against 307.7 on 16; 8 M triangles at 24 levels (+2) on 20 waves 48.8 ms against 50.4 at 27
-// levels (+5) on 16 waves and 54.5 at 24 levels on 16.  So: as many spare levels, up to 5 and at least 2, as keep twenty waves;
-// where even +2 does not (more than ~8 M triangles), up to 5 as long as 14 waves (or as many as +2 levels leave) still fit.
+// levels (+5) on 16 waves and 54.5 at 24 levels on 16 — but with only two spare levels the depth budget forces the builders into
+// their median splits all over the tree (the device builder falls back to the hybrid path: 0.55 s instead of 0.12 s), for 3 %.
+// So: as many spare levels, up to 5 and at least 3, as keep twenty waves (24 levels: up to ~4 M triangles); beyond, up to 5 as
+// long as 14 waves (or as many as +2 levels leave) still fit.
 constexpr int defaultDepthSlack(int levels) {
   if (levels < 19) return 3;
-  for (int s = 5; s >= 2; --s)
+  for (int s = 5; s >= 3; --s)
     if (levels + s < kMaxDepth && fitsTwentyWaves(levels + s)) return s;
   const uint32_t keep = wavesForDepth(levels + 2);
   const uint32_t floorWaves = keep < 14u ? keep : 14u;
@@ -121,7 +123,7 @@ constexpr int defaultDepthSlack(int levels) {
   while (s < 5 && levels + s + 1 < kMaxDepth && wavesForDepth(levels + s + 1) >= floorWaves) ++s;
   return s;
 }
-static_assert(defaultDepthSlack(19) == 5 && defaultDepthSlack(22) == 2 && fitsTwentyWaves(24) && !fitsTwentyWaves(25), "depth policy");
+static_assert(defaultDepthSlack(19) == 5 && defaultDepthSlack(21) == 3 && defaultDepthSlack(22) == 5 && fitsTwentyWaves(24) && !fitsTwentyWaves(25), "depth policy");
 constexpr uint32_t kTopNodes = 4096;  // nodes [0, kTopNodes) are the most-visited top of the tree (LDS candidates)
 
 inline int32_t encodeLeaf(uint32_t first, uint32_t count) { return ~static_cast<int32_t>((first << 3) | (count - 1)); }
@@ -168,7 +170,7 @@ struct TopBuilt {
     uint32_t parent;    // top node that refers to it, and which of its children
     uint32_t slot;
   };
-  std::vector<Node> nodes;      // most-visited first (relayoutTop), child 0 = the smaller box
+  std::vector<Node> nodes;      // most-visited first (relayoutTop), child 0 = the left range of the split
   std::vector<uint32_t> order;  // triangle ids: the leaf order above the parts, each part's range contiguous
   std::vector<Part> parts;      // ascending by b
   uint32_t leafMax = 2, maxDepth = 0;  // maxDepth: deepest leaf / part root of the top

@@ -288,16 +288,23 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
       }
       __syncthreads();
     }
-    // ---- decisions: (axis, split position) per segment; no admissible split (depth budget): the median of the
-    // current order always fits it
+    // ---- decisions: (axis, split position) per segment; no admissible split (the depth budget): the host's medianSplit —
+    // the lower half along the centroid axis of the largest extent (the first of equal ones), in (key, id) order: always fits
     uint32_t ax = 0, kpos = 0;
     if (big) {
-      const unsigned long long bb = best[segS[i]];
-      if (bb == ~0ull) ax = 4u, kpos = segS[i] + (uint32_t)(segE[i] - segS[i]) / 2u;
-      else ax = (uint32_t)(bb >> 16) & 7u, kpos = (uint32_t)bb & 0xffffu;
+      const uint32_t s0 = segS[i], e0 = segE[i];
+      const unsigned long long bb = best[s0];
+      if (bb == ~0ull) {
+        float ext[3];
+        for (int a = 0; a < 3; ++a) ext[a] = eCen[a * T + ordA[a * T + e0 - 1u]] - eCen[a * T + ordA[a * T + s0]];
+        const uint32_t f = ext[1] > ext[0] ? 1u : 0u;
+        ax = ext[2] > ext[f] ? 2u : f, kpos = s0 + (e0 - s0) / 2u;
+      } else {
+        ax = (uint32_t)(bb >> 16) & 7u, kpos = (uint32_t)bb & 0xffffu;
+      }
     }
-    // ---- every triangle to its rank along the chosen axis (ax == 4: stays)
-    const uint32_t np = (big && ax < 4u) ? rnk[ax * T + i] : i;
+    // ---- every triangle to its rank along the chosen axis
+    const uint32_t np = big ? rnk[ax * T + i] : i;
     // ---- the four orders follow: inside a split segment the lefts keep their order in front, the rights theirs behind (the
     // segment arrays are still the old ones here: a sorted position belongs to the same segment on every axis)
     __syncthreads();  // (sufA's last readers are done: nph / cl live there)
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(T) void k_subtree(const SubItem* __restrict__ items
       if (bigP) {
         const uint32_t s0 = segS[i], before = (uint32_t)cl[i] - fl;  // lefts of this segment in front of this position
         const unsigned long long bb = best[s0];
-        const uint32_t kp = bb == ~0ull ? s0 + (uint32_t)(segE[i] - s0) / 2u : (uint32_t)bb & 0xffffu;
+        const uint32_t kp = bb == ~0ull ? s0 + (uint32_t)(segE[i] - s0) / 2u : (uint32_t)bb & 0xffffu;  // (as decided above)
         newpos = rightP ? kp + (i - s0 - before) : s0 + before;
       }
       __syncthreads();
@@ -431,12 +438,8 @@ __global__ void k_sub_relocate(const SubItem* __restrict__ items, const uint32_t
       if (child[q] >= 0) child[q] += (int32_t)base;
     Box3 B0{r[0] - pad, r[1] - pad, r[2] - pad, r[3] + pad, r[4] + pad, r[5] + pad};
     Box3 B1{r[6] - pad, r[7] - pad, r[8] - pad, r[9] + pad, r[10] + pad, r[11] + pad};
-    if (half_area(B1) < half_area(B0)) {  // child 0 = the smaller box (see k_level_emit)
-      const Box3 t = B0;
-      B0 = B1, B1 = t;
-      const int32_t c0 = child[0];
-      child[0] = child[1], child[1] = c0;
-    }
+    // (slot 0 = the left range, as the builders made it: the rotation passes run on the host builder's slot order — its candidate
+    // set is not symmetric in the slots —, and k_rot_pack puts the smaller box into slot 0 afterwards)
     const size_t i = base + k;
     nodesF[4 * i + 0] = make_float4(B0.lx, B0.ly, B0.lz, B0.hx);
     nodesF[4 * i + 1] = make_float4(B0.hy, B0.hz, B1.lx, B1.ly);
@@ -620,7 +623,7 @@ static hipError_t rotate_and_pack(float4* nodesF, uint4* nodes16, uint32_t n, in
                                   uint32_t* maxDepthOut, hipStream_t stream) {
   static const int rotEnv = getenv("RT_BVH_GPU_ROT") ? atoi(getenv("RT_BVH_GPU_ROT")) : -1;
   if (rotEnv >= 0) passes = rotEnv;
-  if (passes <= 0 || n < 2) return hipSuccess;
+  if (n < 2) return hipSuccess;
   RNode* nodes = reinterpret_cast<RNode*>(nodesF);
   uint32_t *parent = nullptr, *scal = nullptr;  // scal: [0] max depth, [1] swaps
   uint8_t *depth = nullptr, *height = nullptr;
@@ -1144,8 +1147,28 @@ __global__ __launch_bounds__(1024) void k_top_sweep(const TopItem* __restrict__ 
     __syncthreads();
   }
   const unsigned long long bb = *best;
-  if (bb == ~0ull) {  // the host would split at the median
-    if (t == 0) atomicExch(needHost, 1u), mid[r] = it.b + n / 2u;
+  if (bb == ~0ull) {
+    // no admissible cut (the depth budget): the host's medianSplit — the lower half along the centroid axis of the largest
+    // extent (the first of equal ones: std::sort's insertion sort of three), in (key, id) order
+    float ext[3];
+    for (int a = 0; a < 3; ++a) ext[a] = funkey(ib[8 * r + 4 + a]) - funkey(ib[8 * r + a]);
+    const int f = ext[1] > ext[0] ? 1 : 0, ax = ext[2] > ext[f] ? 2 : f;
+    for (uint32_t e = 0; e < 4u; ++e) {
+      const uint32_t j = t + kSweepT * e;
+      if (j < n) {
+        const uint32_t id = home[j];
+        key[j] = ((unsigned long long)((uint32_t)fkey(top_centroid(lo[id], hi[id], ax)) ^ 0x80000000u) << 12) | j;
+      } else {
+        key[j] = ~0ull;
+      }
+    }
+    __syncthreads();
+    sweep_sort(key);
+    for (uint32_t e = 0; e < 4u; ++e) {
+      const uint32_t i = t + kSweepT * e;
+      if (i < n) ord[it.b + i] = home[(uint32_t)(key[i] & 4095u)];
+    }
+    if (t == 0) mid[r] = it.b + n / 2u;
     return;
   }
   for (uint32_t e = 0; e < 4u; ++e) {
@@ -1180,8 +1203,8 @@ __global__ __launch_bounds__(256) void k_top_childbox(const TopItem* __restrict_
     for (int s = 0; s < 2; ++s)
       for (int a = 0; a < 3; ++a) atomicMin(&cbx[12 * r + 6 * s + a], mn[3 * s + a]), atomicMax(&cbx[12 * r + 6 * s + 3 + a], mx[3 * s + a]);
 }
-// the node record of every split range (padded child boxes, the smaller box in slot 0 as bvh_build.cpp smallerChildFirst
-// leaves it), its parts registered for k_subtree, its leaves put in ascending id
+// the node record of every split range (padded child boxes, the left range in slot 0), its parts registered for k_subtree, its
+// leaves put in ascending id
 __global__ void k_top_emit(const TopItem* __restrict__ items, uint32_t count, uint32_t depth, const uint32_t* __restrict__ mid,
                            const int32_t* __restrict__ refs, const int* __restrict__ cbx, float pad, uint32_t* __restrict__ ord,
                            RNode* __restrict__ nodes, SubItem* __restrict__ subs) {
@@ -1194,11 +1217,10 @@ __global__ void k_top_emit(const TopItem* __restrict__ items, uint32_t count, ui
     B[s] = top_box_of(cbx + 12 * r + 6 * s);
     B[s].lx -= pad, B[s].ly -= pad, B[s].lz -= pad, B[s].hx += pad, B[s].hy += pad, B[s].hz += pad;
   }
-  const bool swp = half_area(B[1]) < half_area(B[0]);
   RNode N;
   N.pad[0] = N.pad[1] = 0;
   for (int s = 0; s < 2; ++s) {
-    const int slot = swp ? 1 - s : s;
+    const int slot = s;  // (the left range in slot 0: the rotation passes want the host builder's slot order)
     const uint32_t cb = s ? m : it.b, ce = s ? it.e : m;
     int32_t ref = refs[2 * r + s];
     if (ref < 0 && ((~(uint32_t)ref) & rtbvh::kPartFlag)) {
@@ -1553,8 +1575,7 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
     cur.swap(next);
     ++depth;
   }
-  // the top's packed records (the smaller box is in slot 0 already: k_rot_pack changes no slot the parts were registered with)
-  if (nTop) hipLaunchKernelGGL(k_rot_pack, dim3((nTop + 255) / 256), blk, 0, stream, nodes, nTop, P.boxScale, nodes16);
+  // (the top's packed records are written with everybody else's by rotate_and_pack: k_sub_relocate patches the float records)
   const double tTop = msSince();
   uint32_t nTotal = 0, maxDepth = 0;
   GB_TRY(subtrees_and_finish(dVpos, dTriShade, n, nTop, nSub, subs, ord, lo, hi, skey, leafMax, P.depthCap, P.pad, P.boxScale, topMaxDepth, maxNodes,

@@ -94,13 +94,18 @@ def test_frames_on_device_built_tree_vs_oracle(kind, w, h, spp):
     ctx.close()
 
 
+@pytest.mark.parametrize("slack", [None, "0", "2"])
 @pytest.mark.parametrize("kind", ["lowres", "hires", "stress"])
-def test_all_three_builders_build_the_same_tree(kind):
+def test_all_three_builders_build_the_same_tree(kind, slack, monkeypatch):
     """The claim of csrc/bvh_gpu.hip: the device builder (the host builder's split rules as kernels, exact subtrees with the
-    host's four sweep axes and id tie-breaks, the host's rotation passes as kernels) and the hybrid builder (the same below
-    the host's own top) produce THE HOST BUILDER'S TREE — the same boxes over the same triangle sets all the way down, whatever
-    the node numbering and the child slots (tests/treedigest.py)."""
+    host's four sweep axes and id tie-breaks, the host's rotation passes as kernels on the host's slot order) and the hybrid
+    builder (the same below the host's own top) produce THE HOST BUILDER'S TREE — the same boxes over the same triangle sets
+    all the way down, whatever the node numbering and the child slots (tests/treedigest.py).  Also with the depth budget
+    binding (RT_BVH_SLACK = 0: a balanced tree, the builders' median splits everywhere; 2: the budget of the biggest scenes),
+    where the depth checks of the splits and of the rotations decide."""
     from treedigest import context_digest
+    if slack is not None:
+        monkeypatch.setenv("RT_BVH_SLACK", slack)
     s = pyrt.Scene(kind, 32, 32)
     got = {}
     for name, b in (("host", pyrt.BVH_HOST), ("device", pyrt.BVH_DEVICE), ("hybrid", pyrt.BVH_HYBRID)):
