@@ -99,7 +99,7 @@ typedef struct rt_options {
  * RT_BVH_DEVICE: the same split rules as kernels down to parts of <= 1,024 triangles, each part one exact SAH subtree (one
  *                workgroup), then the host's rotation passes and a pre-order numbering as kernels: the SAME tree as
  *                RT_BVH_HOST's (equal boxes and leaf sets on the four preset scenes: tests/treedigest.py), 1 M triangles
- *                in about 20 ms.  A range that needs the host's median split (coincident centroids) makes it take RT_BVH_HYBRID.
+ *                in about 20 ms.
  * RT_BVH_HYBRID: the host builder's own top, stopped at the same parts; everything below as RT_BVH_DEVICE.                 */
 enum { RT_BVH_AUTO = 0, RT_BVH_DEVICE = 1, RT_BVH_HYBRID = 2, RT_BVH_HOST = 3 };
 /* RT_NODES_F16: 32-byte records, 12 binary16 box planes + 2 child refs (two 16-byte requests per visit).

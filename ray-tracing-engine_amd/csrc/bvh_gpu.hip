@@ -19,7 +19,7 @@
 //      subtrees are numbered behind the top (scan of their node counts);
 //   4. the host builder's rotation passes as kernels (one launch per depth, bottom-up), a pre-order renumbering, the
 //      packing with the smaller child box in slot 0; the triangle records in leaf order.
-// The HYBRID build takes step 2 from the host (rtbvh::buildTop) — the fall-back when a range needs the host's median split.
+// The HYBRID build takes step 2 from the host (rtbvh::buildTop).
 // (Rounds 2-3 had a Morton-order top here — radix sort, segment tree of boxes, 64 candidate cuts per range —: +4 ... +7 % node
 // visits against the host tree; removed in round 4, code at commit 286f27d.)
 // Result and cost (profiles/r04_builders.txt): the host builder's node visits per ray to the last digit on all
@@ -696,7 +696,8 @@ static hipError_t rotate_and_pack(float4* nodesF, uint4* nodes16, uint32_t n, in
 // SAME splits come out here, and with them the host builder's tree (tests/test_gpu_bvhbuild.py compares the two), in a few
 // milliseconds for a million triangles instead of the host's 35.  The host keeps what it alone can give bit for bit: the
 // size keys (libm's log2f; rtbvh::planSceneExact).  A range the host would split at its MEDIAN (no admissible SAH split:
-// coincident centroids, a spent depth budget) raises `needHost` and the caller takes the hybrid path (host top) instead.
+// coincident centroids, a spent depth budget) gets the host's medianSplit: in the sweep kernel and in k_subtree directly, for a
+// binned range by a radix selection of the pivot and the same stable partition.
 // One level of the tree per round of launches; the host keeps the list of ranges (a few thousand at most) and reads one
 // split position per range and level.
 constexpr uint32_t kTopChunk = 1024;   // primitives per workgroup of the per-level passes (256 threads x 4)
@@ -845,7 +846,7 @@ __device__ __forceinline__ Box3 top_box_of(const int* B) {
 // the same costs, and the wave picks the minimum of (cost, axis, bin) — the sequential loop's choice.
 __global__ __launch_bounds__(64) void k_top_choose(const TopItem* __restrict__ items, uint32_t count, uint32_t depth, int depthCap,
                                                    uint32_t leafMax, const TopPrep* __restrict__ prep, const int* __restrict__ bins,
-                                                   TopDec* __restrict__ dec, uint32_t* __restrict__ mid, uint32_t* __restrict__ needHost) {
+                                                   TopDec* __restrict__ dec, uint32_t* __restrict__ mid, uint32_t* __restrict__ needMedian) {
   const uint32_t r = blockIdx.x, lane = threadIdx.x;
   if (r >= count) return;
   const TopItem it = items[r];
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(64) void k_top_choose(const TopItem* __restrict__ i
   // the host's median fall-backs: no admissible cut, or an extremely lopsided one deep in the tree
   const uint32_t small = bestLeft < n - bestLeft ? bestLeft : n - bestLeft;
   if (best == ~0ull || (n > 64u && (unsigned long long)small * 64ull < n && (int)depth > rtbvh::kMaxDepth / 2)) {
-    atomicExch(needHost, 1u);
+    atomicExch(needMedian, 1u);  // (a median split: the partition passes leave the range alone, the host selects its pivot)
     dec[r] = TopDec{-1, 0, 0.f, 0.f}, mid[r] = it.b + n / 2u;
     return;
   }
@@ -909,9 +910,32 @@ __global__ __launch_bounds__(64) void k_top_choose(const TopItem* __restrict__ i
   dec[r] = TopDec{bestAxis, bestBin, P.lo[bestAxis], P.scale[bestAxis]};
   mid[r] = it.b + bestLeft;
 }
+// (key, id) of the host's medianSplit order as one 64-bit word
+__device__ __forceinline__ unsigned long long top_median_key(uint32_t id, int axis, const float4* lo, const float4* hi) {
+  return ((unsigned long long)((uint32_t)fkey(top_centroid(lo[id], hi[id], axis)) ^ 0x80000000u) << 32) | id;
+}
 __device__ __forceinline__ bool top_goes_left(const TopDec& D, int NB, uint32_t id, const float4* lo, const float4* hi, const float* skey) {
+  if (D.axis >= 4) {  // a MEDIAN split along axis D.axis - 4: everything below the pivot key {lo, scale} = its two halves' bits
+    const unsigned long long pivot = ((unsigned long long)__float_as_uint(D.lo) << 32) | __float_as_uint(D.scale);
+    return top_median_key(id, D.axis - 4, lo, hi) < pivot;
+  }
   const float v = D.axis == 3 ? skey[id] : top_centroid(lo[id], hi[id], D.axis);
   return top_bin(v, D.lo, D.scale, NB) <= D.bin;
+}
+// radix selection of a range's k-th smallest median key, one byte per pass: the histogram of the byte at `shift` among the keys
+// that agree with `prefix` above it
+__global__ __launch_bounds__(256) void k_top_select_hist(const uint32_t* __restrict__ ord, uint32_t b, uint32_t e, int axis,
+                                                         const float4* __restrict__ lo, const float4* __restrict__ hi,
+                                                         unsigned long long prefix, int shift, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t sh[256];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t p = b + blockIdx.x * 256u + threadIdx.x; p < e; p += gridDim.x * 256u) {
+    const unsigned long long k = top_median_key(ord[p], axis, lo, hi);
+    if (shift >= 56 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&sh[(uint32_t)(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
 // stable partition of the binned ranges, three passes: lefts per workgroup, their prefix per range, the move
 __global__ __launch_bounds__(256) void k_top_count(const TopItem* __restrict__ items, const uint32_t* __restrict__ blkItem,
@@ -1037,7 +1061,7 @@ __global__ __launch_bounds__(1024) void k_top_sweep(const TopItem* __restrict__ 
                                                     uint32_t depth, int depthCap, uint32_t leafMax, const int* __restrict__ ib,
                                                     const float4* __restrict__ lo, const float4* __restrict__ hi,
                                                     const float* __restrict__ skey, uint32_t* __restrict__ ord, uint32_t* __restrict__ tmp,
-                                                    uint32_t* __restrict__ mid, uint32_t* __restrict__ needHost) {
+                                                    uint32_t* __restrict__ mid) {
   extern __shared__ unsigned long long sweep_lds[];
   unsigned long long* key = sweep_lds;                          // [4096] sort keys
   float* sc = reinterpret_cast<float*>(key + kSweepN);          // [6][4096] boxes in sorted order / their scans
@@ -1423,11 +1447,9 @@ hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, co
 // The EXACT device build (rt_options.bvh_builder = RT_BVH_DEVICE, and what RT_BVH_AUTO takes for big scenes): the host
 // builder's split rules as kernels for the ranges above kSubMax triangles (k_top_*), then the exact subtrees, the rotation
 // passes and the numbering every device build ends with.  `hSizeKey`: the host's size keys (rtbvh::planSceneExact).
-// *needHost = true (and nothing built): a range needs the host's median split — the caller takes the hybrid path.
 hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const float* hSizeKey, uint32_t n, const rtbvh::ScenePlan& P,
-                               GpuBvh* out, bool* needHost, hipStream_t stream) {
+                               GpuBvh* out, hipStream_t stream) {
   *out = GpuBvh{};
-  *needHost = false;
   if (n == 0 || !hSizeKey) return hipErrorInvalidValue;
   const uint32_t leafMax = P.leafMax;
   const uint32_t maxItems = n / kSubMax + 2u;              // ranges of one level: disjoint, more than kSubMax triangles each
@@ -1442,7 +1464,9 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
                oPrep = A.reserve((size_t)maxItems * sizeof(TopPrep)), oDec = A.reserve((size_t)maxItems * sizeof(TopDec)),
                oMid = A.reserve((size_t)maxItems * 4), oRefs = A.reserve((size_t)maxItems * 8), oCbx = A.reserve((size_t)maxItems * 48),
                oBlockLeft = A.reserve((size_t)maxBlk * 4), oBins = A.reserve((size_t)maxBinned * 4u * 64u * 7u * 4u),
-               oFlag = A.reserve(8), oSubs = A.reserve((size_t)maxSub * sizeof(SubItem));
+               oFlag = A.reserve(8), oSubs = A.reserve((size_t)maxSub * sizeof(SubItem)), oItems2 = A.reserve(sizeof(TopItem)),
+               oDec2 = A.reserve(sizeof(TopDec)), oMid2 = A.reserve(8), oBlkItem2 = A.reserve((size_t)maxBlk * 4),
+               oBlockLeft2 = A.reserve((size_t)maxBlk * 4), oHist = A.reserve(256 * 4);
   float4 *nodesF = nullptr, *tris = nullptr, *trisRef = nullptr;
   uint4* nodes16 = nullptr;
   bool keepOutputs = false;
@@ -1461,7 +1485,9 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
   float* skey = A.at<float>(oKey);
   uint32_t *ord = A.at<uint32_t>(oOrd), *tmp = A.at<uint32_t>(oTmp), *blkItem = A.at<uint32_t>(oBlkItem), *sweepList = A.at<uint32_t>(oSweep),
            *mid = A.at<uint32_t>(oMid), *blockLeft = A.at<uint32_t>(oBlockLeft), *flag = A.at<uint32_t>(oFlag);
-  TopItem* items = A.at<TopItem>(oItems);
+  TopItem *items = A.at<TopItem>(oItems), *items2 = A.at<TopItem>(oItems2);
+  TopDec* dec2 = A.at<TopDec>(oDec2);
+  uint32_t *mid2 = A.at<uint32_t>(oMid2), *blkItem2 = A.at<uint32_t>(oBlkItem2), *blockLeft2 = A.at<uint32_t>(oBlockLeft2), *hist = A.at<uint32_t>(oHist);
   int *ib = A.at<int>(oIb), *cbx = A.at<int>(oCbx), *bins = A.at<int>(oBins);
   TopPrep* prep = A.at<TopPrep>(oPrep);
   TopDec* dec = A.at<TopDec>(oDec);
@@ -1533,7 +1559,7 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
     }
     if (nSweep)
       hipLaunchKernelGGL(k_top_sweep, dim3(nSweep), dim3(kSweepT), kSweepLds, stream, items, sweepList, depth, P.depthCap, leafMax, ib, lo, hi,
-                         skey, ord, tmp, mid, flag);
+                         skey, ord, tmp, mid);
     hMid.resize(count);
     uint32_t hostFlag = 0;
     GB_TRY(hipMemcpyAsync(hMid.data(), mid, (size_t)count * 4, hipMemcpyDeviceToHost, stream));
@@ -1541,9 +1567,59 @@ hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const
     GB_TRY(hipStreamSynchronize(stream));
     GB_TRY(hipGetLastError());
     if (hostFlag) {
-      cleanup();
-      *needHost = true;
-      return hipSuccess;
+      // Binned ranges the host would cut at its MEDIAN (no admissible SAH cut, or the lopsided-split guard): medianSplit is the
+      // lower half in (centroid along the axis of the largest extent, id) order.  The pivot — the n/2-th smallest 64-bit key — by
+      // radix selection, a byte per pass; then the same stable partition as the binned cuts, with "key < pivot" as its test.
+      std::vector<TopDec> hDec(count);
+      std::vector<int> hIb(8 * (size_t)count);
+      GB_TRY(hipMemcpyAsync(hDec.data(), dec, (size_t)count * sizeof(TopDec), hipMemcpyDeviceToHost, stream));
+      GB_TRY(hipMemcpyAsync(hIb.data(), ib, (size_t)count * 32, hipMemcpyDeviceToHost, stream));
+      GB_TRY(hipMemsetAsync(flag, 0, 8, stream));
+      GB_TRY(hipStreamSynchronize(stream));
+      auto unkey = [](int i) {
+        const int b = i >= 0 ? i : i ^ 0x7fffffff;
+        float f;
+        memcpy(&f, &b, 4);
+        return f;
+      };
+      auto bitsf = [](uint32_t u) {
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+      };
+      for (uint32_t r = 0; r < count; ++r) {
+        if (!hItems[r].nb || hDec[r].axis != -1) continue;
+        const uint32_t rb = hItems[r].b, re = hItems[r].e, rn = re - rb, rBlk = (rn + kTopChunk - 1u) / kTopChunk;
+        float ext[3];
+        for (int a = 0; a < 3; ++a) ext[a] = unkey(hIb[8 * (size_t)r + 4 + a]) - unkey(hIb[8 * (size_t)r + a]);
+        const int f0 = ext[1] > ext[0] ? 1 : 0, ax = ext[2] > ext[f0] ? 2 : f0;  // (std::sort's insertion sort of three: the first of equal extents)
+        unsigned long long prefix = 0;
+        uint32_t k = rn / 2u;  // (0-based rank of the pivot: exactly n / 2 keys lie below it — the keys are distinct)
+        for (int shift = 56; shift >= 0; shift -= 8) {
+          uint32_t hh[256];
+          GB_TRY(hipMemsetAsync(hist, 0, 256 * 4, stream));
+          const uint32_t g = (rn + 255u) / 256u < 1024u ? (rn + 255u) / 256u : 1024u;
+          hipLaunchKernelGGL(k_top_select_hist, dim3(g), blk, 0, stream, ord, rb, re, ax, lo, hi, prefix, shift, hist);
+          GB_TRY(hipMemcpyAsync(hh, hist, sizeof hh, hipMemcpyDeviceToHost, stream));
+          GB_TRY(hipStreamSynchronize(stream));
+          uint32_t j = 0;
+          while (j < 255u && k >= hh[j]) k -= hh[j], ++j;
+          prefix |= (unsigned long long)j << shift;
+        }
+        hDec[r] = TopDec{4 + ax, 0, bitsf((uint32_t)(prefix >> 32)), bitsf((uint32_t)prefix)};
+        TopItem mi = hItems[r];
+        mi.blk0 = 0;
+        GB_TRY(hipMemcpyAsync(items2, &mi, sizeof mi, hipMemcpyHostToDevice, stream));
+        GB_TRY(hipMemcpyAsync(dec2, &hDec[r], sizeof(TopDec), hipMemcpyHostToDevice, stream));
+        GB_TRY(hipMemcpyAsync(mid2, &hMid[r], 4, hipMemcpyHostToDevice, stream));
+        GB_TRY(hipMemsetAsync(blkItem2, 0, (size_t)rBlk * 4, stream));
+        hipLaunchKernelGGL(k_top_count, dim3(rBlk), blk, 0, stream, items2, blkItem2, ord, lo, hi, skey, dec2, blockLeft2);
+        hipLaunchKernelGGL(k_top_offsets, dim3(1), dim3(64), 0, stream, items2, blockLeft2);
+        hipLaunchKernelGGL(k_top_scatter, dim3(rBlk), blk, 0, stream, items2, blkItem2, ord, lo, hi, skey, dec2, mid2, blockLeft2, tmp);
+        hipLaunchKernelGGL(k_top_copyback, dim3(rBlk), blk, 0, stream, items2, blkItem2, tmp, ord);
+        GB_TRY(hipStreamSynchronize(stream));  // (mi, hDec[r] and hMid[r] are read by the copies above)
+      }
+      GB_TRY(hipGetLastError());
     }
     // the children: leaves (<= leafMax), parts (<= kSubMax: one exact subtree each), or ranges of the next level
     next.clear(), hRefs.resize(2 * (size_t)count);

@@ -516,25 +516,10 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
       fprintf(stderr, "scene arrays on the device %.2f ms after the start\n", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tBuild0).count());
     rtk::GpuBvh G;
     hipError_t he = hipSuccess;
-    bool fellBack = false;
     if (hybrid) {
       he = rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sizeKey.data(), sc->n_triangles, topBuilt, &G, nullptr);
     } else {
-      bool needHost = false;
-      he = rtk::gpu_bvh_build_exact(S.vpos, S.triShade, sizeKey.data(), sc->n_triangles, plan, &G, &needHost, nullptr);
-      if (he == hipSuccess && needHost) {
-        // a range the host builder would cut at its median (coincident centroids, a spent depth budget): the host's top it is
-        try {
-          rtbvh::buildTop(*sc, opt ? opt->bvh_leaf_max : 0, 1024u, topBuilt);
-        } catch (const std::exception& e) {
-          rt_destroy(c);
-          return fail(RT_ERR_INVALID, "scene rejected: %s", e.what());
-        }
-        c->bvh.depthCap = topBuilt.depthCap;
-        he = rtk::gpu_bvh_build_over_top(S.vpos, S.triShade, sizeKey.data(), sc->n_triangles, topBuilt, &G, nullptr);
-        fellBack = true;
-        if (getenv("RT_BVH_VERBOSE")) fprintf(stderr, "exact device build: a range needs the host's median split; hybrid build instead\n");
-      }
+      he = rtk::gpu_bvh_build_exact(S.vpos, S.triShade, sizeKey.data(), sc->n_triangles, plan, &G, nullptr);
     }
     if (he != hipSuccess) {
       rt_destroy(c);
@@ -545,7 +530,7 @@ int create_ctx(const rt_scene_desc* sc, const rt_options* opt, const rtbvh::Buil
     c->dNodesF = G.nodesF;
     c->bvh.maxDepth = G.maxDepth;
     S.n_nodes = G.n_nodes;
-    c->builder = (hybrid || fellBack) ? RT_BVH_HYBRID : RT_BVH_DEVICE;
+    c->builder = hybrid ? RT_BVH_HYBRID : RT_BVH_DEVICE;
     // Trees whose top the render kernel may keep in LDS (rt_kernels.hip plan_persist: a prefix of the node array) get the host
     // builder's final numbering — the most-visited nodes first, greedily by box area from the root (bvh_build.cpp
     // relayoutTop) — instead of the device's pre-order: C4 loses 2 % on a pre-order tree.  64 KB ... 4 MB back and forth.

@@ -120,10 +120,9 @@ struct GpuBvh {
   float4* trisRef = nullptr;  // reference order
   uint32_t n_nodes = 0, maxDepth = 0;
 };
-// the exact build: the host builder's split rules as kernels above the exact subtrees (hSizeKey: rtbvh::planSceneExact);
-// *needHost: a range needs the host's median split, nothing was built — take the hybrid build
+// the exact build: the host builder's split rules as kernels above the exact subtrees (hSizeKey: rtbvh::planSceneExact)
 hipError_t gpu_bvh_build_exact(const float* dVpos, const uint4* dTriShade, const float* hSizeKey, uint32_t n_tris, const rtbvh::ScenePlan& plan,
-                               GpuBvh* out, bool* needHost, hipStream_t stream);
+                               GpuBvh* out, hipStream_t stream);
 // the hybrid build: the host builder's top (rtbvh::buildTop), exact subtrees of its parts on the device
 hipError_t gpu_bvh_build_over_top(const float* dVpos, const uint4* dTriShade, const float* hSizeKey, uint32_t n_tris, const rtbvh::TopBuilt& top,
                                   GpuBvh* out, hipStream_t stream);

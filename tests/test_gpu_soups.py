@@ -17,9 +17,11 @@ N = 140000
 @pytest.mark.parametrize("n", [N, 9000, 3000])  # (swept and binned ranges at the top; just above RT_BVH_AUTO's threshold; swept only)
 @pytest.mark.parametrize("kind", soups.KINDS)
 def test_every_builder_is_exact_on_hard_soups(kind, n):
+    from treedigest import context_digest
     s = soups.soup(kind, n)
     rays = soups.soup_rays(s, 3000)
     want = None
+    digests = {}
     for builder, fmt in ((pyrt.BVH_AUTO, pyrt.NODES_AUTO), (pyrt.BVH_HOST, pyrt.NODES_F16), (pyrt.BVH_DEVICE, pyrt.NODES_F16),
                          (pyrt.BVH_HYBRID, pyrt.NODES_Q8), (pyrt.BVH_DEVICE, pyrt.NODES_Q8)):
         ctx = pyrt.Context(s, bvh_builder=builder, node_format=fmt)
@@ -34,7 +36,14 @@ def test_every_builder_is_exact_on_hard_soups(kind, n):
         got = ctx.trace(rays, pyrt.ACCEL_BVH)
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (kind, builder, fmt)
         assert np.array_equal(ctx.trace(rays, pyrt.ACCEL_BVH, pyrt.TRACE_ANY)["hit"], want["hit"]), (kind, builder, fmt)
+        if fmt == pyrt.NODES_F16 and builder in (pyrt.BVH_HOST, pyrt.BVH_DEVICE):
+            digests[builder] = (context_digest(ctx), bi.n_nodes, bi.max_depth)
         ctx.close()
+    # ... and the device builder builds the host builder's tree on these too (coincident triangles: median splits by id all the
+    # way down, the binned ones through the radix selection of bvh_gpu.hip)
+    import os
+    if not os.environ.get("RT_BVH_GPU"):
+        assert digests[pyrt.BVH_DEVICE] == digests[pyrt.BVH_HOST], (kind, n, digests)
 
 
 @pytest.mark.parametrize("kind", ["corner", "random"])
