@@ -110,7 +110,7 @@ constexpr bool fitsTwentyWaves(int depth) {
 // all 14 waves = 73.3 / 71.7 / 71.8 / 63.9 ms, +6 (13 waves) 68.6 ms.  Round 4, with the 20-wave configuration: 1 M triangles at
 // 24 levels (+5) 276.9 ms on 20 waves against 307.7 on 16; 8 M triangles at 24 levels (+2) on 20 waves 48.8 ms against 50.4 at 27
 // levels (+5) on 16 waves and 54.5 at 24 levels on 16 — but with only two spare levels the depth budget forces the builders into
-// their median splits all over the tree (the device builder falls back to the hybrid path: 0.55 s instead of 0.12 s), for 3 %.
+// their median splits all over the tree (41.8 instead of 39.1 node visits per ray; one lattice scene is the evidence), for 3 %.
 // So: as many spare levels, up to 5 and at least 3, as keep twenty waves (24 levels: up to ~4 M triangles); beyond, up to 5 as
 // long as 14 waves (or as many as +2 levels leave) still fit.
 constexpr int defaultDepthSlack(int levels) {
