@@ -192,7 +192,7 @@ def test_build_time_and_tree_quality_report(capsys):
             assert out[name][1:3] == out["host"][1:3], (kind, name, out)  # nodes, depth
             # visits and tests per ray: equal — except on the one-request records (RT_NODES=q8 forced), whose 8-bit planes are
             # quantised in the frames of 16-KiB blocks of the node ARRAY, so they depend on the numbering too
-            tol = 2e-3 if os.environ.get("RT_NODES") else 0.0
+            tol = 1e-2 if os.environ.get("RT_NODES") else 0.0
             assert abs(out[name][3] / out["host"][3] - 1) <= tol and abs(out[name][4] / out["host"][4] - 1) <= tol, (kind, name, out)
     stress = dict(rows)["stress"]
     if not os.environ.get("RT_BVH_GPU") and not os.environ.get("RT_NODES"):  # (forced builders / the host-side Q8 packing in every build)

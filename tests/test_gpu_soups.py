@@ -66,6 +66,9 @@ def test_device_builder_with_other_leaf_sizes(leaf):
     """rt_options.bvh_leaf_max 1 ... 8 through the device builder (parts, top leaves and the depth budget all depend on it):
     exact, and the same tree as the host builder's."""
     from treedigest import context_digest
+    import os
+    if leaf > 2 and os.environ.get("RT_NODES") == "q8":
+        pytest.skip("the one-request records hold leaves of at most 2 triangles")
     for s in (pyrt.Scene("hires", 16, 16), soups.soup("random", 20000)):
         rays = soups.soup_rays(s, 2000) if isinstance(s, pyrt.ArrayScene) else None
         got = {}
