@@ -95,10 +95,10 @@ constexpr uint32_t wavesForDepth(int depth) {
   const uint32_t w = kLdsWordsPerCU / ((uint32_t)(depth + 1) * kStackRowWords + kWavePoolWords);
   return w < 16u ? w : 16u;
 }
-// Round 4: TWENTY waves per CU for the big trees — five workgroups of four waves at 96 VGPRs with the smallest ray pool (360
-// words; rt_kernels.hip LT_COMPACT3) — fit while the tree is at most 24 levels deep (the LDS is handed out in units of 1,280
-// bytes: 16 x (25 rows x 64 + 360) words = 31,360 B -> 32,000 per workgroup, five of them 160,000 of 163,840).
-constexpr uint32_t kWavePoolWordsMin = 360u, kLdsGrainBytes = 1280u;
+// Round 4: TWENTY waves per CU for the big trees — five workgroups of four waves at 96 VGPRs with the smallest ray pool (168
+// words; rt_kernels.hip LT_COMPACT3) — fit while the tree is at most 27 levels deep (the LDS is handed out in units of 1,280
+// bytes: 16 x (28 rows x 64 + 168) words = 31,360 B -> 32,000 per workgroup, five of them 160,000 of 163,840).
+constexpr uint32_t kWavePoolWordsMin = 168u, kLdsGrainBytes = 1280u;
 constexpr bool fitsTwentyWaves(int depth) {
   return 5u * ((((uint32_t)(depth + 1) * kStackRowWords + kWavePoolWordsMin) * 16u + kLdsGrainBytes - 1u) / kLdsGrainBytes * kLdsGrainBytes) <=
          kLdsWordsPerCU * 4u;
@@ -107,12 +107,10 @@ constexpr bool fitsTwentyWaves(int depth) {
 // From 19 balanced levels up a level costs waves (256 B of LDS per wave and level), and the trade was
 // measured on the lattice scenes.  Round 2, at 14-16 waves: 1 M triangles (19 levels) +2 / +3 / +4 / +5 spare levels = 16 / 15 /
 // 15 / 14 waves = 402 / 415 / 416 / 393 ms with 37.5 / 36.7 / 36.7 / 35.0 node visits per ray; 8 M triangles (22 levels) +2 ... +5
-// all 14 waves = 73.3 / 71.7 / 71.8 / 63.9 ms, +6 (13 waves) 68.6 ms.  Round 4, with the 20-wave configuration: 1 M triangles at
-// 24 levels (+5) 276.9 ms on 20 waves against 307.7 on 16; 8 M triangles at 24 levels (+2) on 20 waves 48.8 ms against 50.4 at 27
-// levels (+5) on 16 waves and 54.5 at 24 levels on 16 — but with only two spare levels the depth budget forces the builders into
-// their median splits all over the tree (41.8 instead of 39.1 node visits per ray; one lattice scene is the evidence), for 3 %.
-// So: as many spare levels, up to 5 and at least 3, as keep twenty waves (24 levels: up to ~4 M triangles); beyond, up to 5 as
-// long as 14 waves (or as many as +2 levels leave) still fit.
+// all 14 waves = 73.3 / 71.7 / 71.8 / 63.9 ms, +6 (13 waves) 68.6 ms.  Round 4, with the 20-wave configuration (trees of up to 27
+// levels): 1 M triangles at 24 levels (+5) 276.9 ms on 20 waves against 307.7 on 16.  So: as many spare levels, up to 5 and at
+// least 3, as keep twenty waves; beyond (more than ~16 M triangles), up to 5 as long as 14 waves (or as many as +2 levels leave)
+// still fit.
 constexpr int defaultDepthSlack(int levels) {
   if (levels < 19) return 3;
   for (int s = 5; s >= 3; --s)
@@ -123,7 +121,7 @@ constexpr int defaultDepthSlack(int levels) {
   while (s < 5 && levels + s + 1 < kMaxDepth && wavesForDepth(levels + s + 1) >= floorWaves) ++s;
   return s;
 }
-static_assert(defaultDepthSlack(19) == 5 && defaultDepthSlack(21) == 3 && defaultDepthSlack(22) == 5 && fitsTwentyWaves(24) && !fitsTwentyWaves(25), "depth policy");
+static_assert(defaultDepthSlack(19) == 5 && defaultDepthSlack(22) == 5 && defaultDepthSlack(23) == 4 && fitsTwentyWaves(27) && !fitsTwentyWaves(28), "depth policy");
 constexpr uint32_t kTopNodes = 4096;  // nodes [0, kTopNodes) are the most-visited top of the tree (LDS candidates)
 
 inline int32_t encodeLeaf(uint32_t first, uint32_t count) { return ~static_cast<int32_t>((first << 3) | (count - 1)); }

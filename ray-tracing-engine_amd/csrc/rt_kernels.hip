@@ -194,11 +194,12 @@ constexpr int LT_COMPACT = 16;
 // holds the direction anyway; a lane that steals part of a bounce ray takes the direction from the
 // victim's registers.  The eight-million-triangle scene's sixteenth wave.
 constexpr int LT_COMPACT2 = 32;
-// ... and without the light samples' parameters either (implies LT_COMPACT2): the pixel lane keeps its RNG state from before
-// its light draws in a register and every use re-draws the sample from there — a worker lane fetches the state by lane
-// shuffle —: the same engine calls, the same bits.  360 words instead of 744: with the 25 stack rows of the 1 M-triangle tree
-// that is 7,840 B per wave — five workgroups of four waves fit a CU's LDS (which is handed out in 1,280-byte units: 8,096 B
-// per wave did not) —, TWENTY waves per CU, and the instance is compiled for five waves per SIMD (96 VGPRs).
+// ... and without the light samples' parameters or the vertex positions either (implies LT_COMPACT2): the pixel lane keeps its
+// vertex and its RNG state from before its light draws in registers, a worker lane fetches both by lane shuffle and re-draws
+// the light sample from the state — the same engine calls, the same bits.  168 words instead of 744 (the bounce keys, the
+// hand-out list, the result bits): with 28 stack rows that is 7,840 B per wave — five workgroups of four waves fit a CU's LDS,
+// which is handed out in 1,280-byte units —, TWENTY waves per CU for trees of up to 27 levels, and the instance is compiled
+// for five waves per SIMD (96 VGPRs).
 constexpr int LT_COMPACT3 = 64;
 // 1 / det of the triangle test by rtd::recip_fast (3 instructions, the division's bits for |det| < 2^100) instead of the
 // division: only the instances the launcher picks when the host has bounded |det| for the launch's rays (DevScene::slowRecip == 0).
@@ -801,9 +802,9 @@ constexpr int VP_PT = 0, VP_DIR = 192, VP_BDIR = VP_DIR + 192 * POOL_L, VP_KEY =
 constexpr int VP_WORDS = VP_RES + 2 * POOL_L + 2;
 constexpr int VP_COMPACT_SAVES = 64 * POOL_L;  // words a compact pool is shorter by
 // offsets of everything behind the per-light block, by layout
-template <int CP> struct VpLayout {  // CP = 0: full, 1: light parameters, 2: ... and no bounce directions, 3: ... and one RNG word for the lights
+template <int CP> struct VpLayout {  // CP = 0: full, 1: light parameters, 2: ... and no bounce directions, 3: keys, list and result bits only
   static constexpr int PER_LIGHT = CP ? 128 : 192;
-  static constexpr int BDIR = CP == 3 ? VP_DIR : VP_DIR + PER_LIGHT * POOL_L, KEY = BDIR + (CP >= 2 ? 0 : 192), LIST = KEY + 128, RES = LIST + 32;
+  static constexpr int BDIR = CP == 3 ? 0 : VP_DIR + PER_LIGHT * POOL_L, KEY = BDIR + (CP >= 2 ? 0 : 192), LIST = KEY + 128, RES = LIST + 32;
   static constexpr int WORDS = RES + 2 * POOL_L + 2;
 };
 static_assert(VpLayout<3>::WORDS == (int)rtbvh::kWavePoolWordsMin && VpLayout<3>::KEY % 2 == 0, "the smallest pool (bvh_build.h sizes the depth cap with it)");
@@ -836,7 +837,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   PH(PH_VSETUP);
   PHC(PH_N_POOLS);
   if (alive) {
-    fp[VP_PT + lane] = point.x, fp[VP_PT + 64 + lane] = point.y, fp[VP_PT + 128 + lane] = point.z;
+    if (!CP3) fp[VP_PT + lane] = point.x, fp[VP_PT + 64 + lane] = point.y, fp[VP_PT + 128 + lane] = point.z;
     // draw order of the reference: the light samples in light order (Renderer.cpp:52),
     // then the hemisphere sample (Renderer.cpp:164)
     if (CP3) gsave = g.s;  // (the light samples are re-drawn from here wherever they are needed)
@@ -965,8 +966,9 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
       PH(PH_STEAL);
     }
     const uint32_t gsj = CP3 ? (uint32_t)__shfl((int)gsave, (int)newJ, 64) : 0u;  // (all lanes take part)
+    const f3 pj3 = CP3 ? mk(__shfl(point.x, (int)newJ, 64), __shfl(point.y, (int)newJ, 64), __shfl(point.z, (int)newJ, 64)) : mk(0.f, 0.f, 0.f);
     if (newRay) {
-      const f3 pj = mk(fp[VP_PT + newJ], fp[VP_PT + 64 + newJ], fp[VP_PT + 128 + newJ]);
+      const f3 pj = CP3 ? pj3 : mk(fp[VP_PT + newJ], fp[VP_PT + 64 + newJ], fp[VP_PT + 128 + newJ]);
       f3 dj;
       if (CP) {
         if (newK < nl) {  // rebuild the direction from the light sample's two parameters
@@ -1025,7 +1027,7 @@ RT_DEV f3 vertex_pool(const DevScene& S, bool alive, bool bounce, Rng& g, f3 ray
   PH(PH_POOLMISC);
   // `point` and the bounce direction come back from the pool (the same bits; lanes without a
   // vertex read stale words nobody uses): nothing of them is live while the wave traverses
-  const f3 pt = mk(fp[VP_PT + lane], fp[VP_PT + 64 + lane], fp[VP_PT + 128 + lane]);
+  const f3 pt = CP3 ? point : mk(fp[VP_PT + lane], fp[VP_PT + 64 + lane], fp[VP_PT + 128 + lane]);
   point = pt;
   if (bounce && !CP2) bdir = mk(fp[VP::BDIR + lane], fp[VP::BDIR + 64 + lane], fp[VP::BDIR + 128 + lane]);
   if (alive) {
@@ -1285,7 +1287,9 @@ RT_DEV void persist_body(const DevScene& S, const RenderArgs& A, float4* __restr
   uint32_t* mine = g_lds + 8u * S.topK + wv * A.waveWords;
   Lds L = carve_lds<false>(mine, A.stackLevels, 0);
   uint32_t* pool = mine + A.stackLevels * BLOCK;
-  float* ex = reinterpret_cast<float*>(pool);
+  // (the 256-word exchange area of the sample adds: in the pool — or, where the pool is smaller than that, in the stack rows,
+  // which are idle between two vertices; Trav::start rewrites the sentinel row)
+  float* ex = reinterpret_cast<float*>((LT & LT_COMPACT3) ? mine : pool);
   LaneStats st;
 #ifdef RT_PHASE_TIMING
   if (threadIdx.x < 24) g_phAcc[threadIdx.x] = 0;
